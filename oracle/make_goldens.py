@@ -1,0 +1,487 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+TEST INFRASTRUCTURE ONLY.  Runs in the build container (where /root/reference
+exists), never on the GPU box.  It imports the reference's own Python model
+(`/root/reference/src/multi_modal/*`, `models/masker.py`, `trainer/base.py`),
+feeds it seeded synthetic inputs and stores inputs + outputs as small .npz/.json
+fixtures.  No reference source text is stored: fixtures are data only.
+
+    cd /root/repo && python oracle/make_goldens.py
+
+Fixture list follows SURVEY.md §8c.
+"""
+import json
+import os
+import random
+import sys
+import types
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("MMFM_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(REF, "src"))
+os.chdir(REF)  # the reference's config paths are cwd-relative
+
+import numpy as np
+import torch
+
+torch.set_num_threads(8)
+
+from multi_modal.mm import MultiModal  # noqa: E402  (reference)
+from multi_modal.encoder_embeddings import EncoderEmbedding  # noqa: E402
+from multi_modal.decoder_embeddings import DecoderEmbedding  # noqa: E402
+from models.masker import Masker  # noqa: E402
+from utils.config_utils import config_from_kwargs, update_config, DictConfig  # noqa: E402
+
+
+# --------------------------------------------------------------------------- helpers
+def ref_config():
+    cfg = config_from_kwargs({"model": "include:src/configs/multi_modal/mm.yaml"})
+    cfg = update_config("src/configs/multi_modal/trainer_mm.yaml", cfg)
+    return cfg
+
+
+def plain(d):
+    """DictConfig -> plain nested dict (deep copy)."""
+    return json.loads(json.dumps(d))
+
+
+def tiny_model_cfg(H=32, heads=4, inter=64, n_enc=1, n_dec=1, max_F=8, dropout=0.0,
+                   emb_dropout=0.0, sep=False, causal=False, n_modality=2):
+    m = plain(ref_config()["model"])
+    for side in ("encoder", "decoder"):
+        m[side]["embedder"].update(max_F=max_F, dropout=emb_dropout, n_modality=n_modality)
+        m[side]["transformer"].update(hidden_size=H, n_heads=heads, inter_size=inter,
+                                      dropout=dropout)
+    m["encoder"]["transformer"]["n_layers"] = n_enc
+    m["decoder"]["transformer"]["n_layers"] = n_dec
+    m["decoder"]["decoder_sep_mask"] = sep
+    m["decoder"]["decoder_causal_mask"] = causal
+    return DictConfig(m)
+
+
+def build_model(model_cfg, n_ap, n_beh, seed):
+    """Construction order of train_multi_modal.py:160-189."""
+    torch.manual_seed(seed)
+    enc, dec = {}, {}
+    for mod in ("ap", "behavior"):
+        enc[mod] = EncoderEmbedding(hidden_size=model_cfg.encoder.transformer.hidden_size,
+                                    n_channel=n_ap if mod == "ap" else n_beh,
+                                    config=model_cfg.encoder)
+    for mod in ("ap", "behavior"):
+        dec[mod] = DecoderEmbedding(hidden_size=model_cfg.decoder.transformer.hidden_size,
+                                    n_channel=n_ap if mod == "ap" else n_beh,
+                                    output_channel=n_ap if mod == "ap" else n_beh,
+                                    config=model_cfg.decoder)
+    return MultiModal(enc, dec, avail_mod=["ap", "behavior"], config=model_cfg,
+                      share_modality_embeddings=True)
+
+
+def synth_batch(B, T, n_ap, n_beh, seed, pad=None, ts_shift=None):
+    """SURVEY.md §8d synthetic recipe; `pad[b]` = number of right-padded bins."""
+    g = torch.Generator().manual_seed(seed)
+    spikes = torch.poisson(torch.full((B, T, n_ap), 0.3), generator=g)
+    beh = torch.randn(B, T, n_beh, generator=g)
+    attn = torch.ones(B, T, dtype=torch.int64)
+    if pad is not None:
+        for b, p in enumerate(pad):
+            if p:
+                attn[b, T - p:] = 0
+    ts = torch.arange(T, dtype=torch.int64)[None].repeat(B, 1)
+    if ts_shift is not None:
+        ts = (ts + torch.tensor(ts_shift)[:, None]) % T
+    return dict(spikes_data=spikes, target=beh, time_attn_mask=attn, spikes_timestamps=ts)
+
+
+def make_mod_dict(batch, objective, regions=None):
+    """What MultiModalTrainer._forward_model_outputs builds (trainer/base.py:51-103)."""
+    spikes, beh = batch["spikes_data"], batch["target"]
+    B, T, n_ap = spikes.shape
+    md = {}
+    for i, mod in enumerate(("ap", "behavior")):
+        d = dict(inputs_modality=torch.tensor(i), targets_modality=torch.tensor(i),
+                 inputs_attn_mask=batch["time_attn_mask"],
+                 inputs_timestamp=batch["spikes_timestamps"],
+                 targets_timestamp=batch["spikes_timestamps"],
+                 eid="synthetic", num_neuron=n_ap, masking_mode=None)
+        x = spikes if mod == "ap" else beh
+        d["inputs"], d["targets"] = x.clone(), x.clone()
+        if mod == "ap":
+            d["inputs_regions"] = regions if regions is not None else np.full((B, n_ap), "XX")
+        md[mod] = d
+    if objective == "encoding":
+        md["ap"]["eval_mask"] = torch.ones_like(spikes).to(torch.int64)
+        md["behavior"]["eval_mask"] = torch.zeros_like(spikes).to(torch.int64)
+    elif objective == "decoding":
+        md["behavior"]["eval_mask"] = torch.ones_like(beh).to(torch.int64)
+        md["ap"]["eval_mask"] = torch.zeros_like(beh).to(torch.int64)
+    elif objective == "token_masking":
+        md["ap"]["eval_mask"] = None
+        md["behavior"]["eval_mask"] = None
+    else:
+        raise ValueError(objective)
+    return md
+
+
+def npify(t):
+    return t.detach().cpu().numpy()
+
+
+def save_npz(name, **arrs):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrs)
+    print(f"  wrote {name}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def save_json(name, obj):
+    path = os.path.join(OUT, name)
+    with open(path, "w") as f:
+        json.dump(obj, f, indent=0, separators=(",", ":"))
+    print(f"  wrote {name}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+# --------------------------------------------------------------------------- fixtures
+def fx_init_order():
+    cfg = ref_config()
+    model = build_model(cfg.model, 668, 2, seed=42)
+    entries = []
+    for k, v in model.state_dict().items():
+        f = v.detach().double().flatten()
+        entries.append(dict(key=k, shape=list(v.shape), sum=float(f.sum()),
+                            abssum=float(f.abs().sum()),
+                            first=[float(x) for x in v.detach().flatten()[:4]]))
+    named = [k for k, _ in model.named_parameters()]
+    save_json("init_order.json", dict(
+        seed=42, n_state=len(entries), n_param=len(named),
+        numel_state=int(sum(np.prod(e["shape"]) for e in entries)),
+        numel_param=int(sum(p.numel() for p in model.parameters())),
+        named_parameters=named, state_dict=entries))
+
+
+def fx_tiny_fwd_bwd():
+    """Tiny config: every tensor of the forward, loss and all grads, three objectives."""
+    B, T, n_ap, n_beh = 2, 8, 12, 2
+    arrs = {}
+    meta = dict(B=B, T=T, n_ap=n_ap, n_beh=n_beh, H=32, heads=4, inter=64,
+                n_enc=1, n_dec=1, max_F=8, model_seed=7, data_seed=3, cases=[])
+    variants = [
+        ("base", dict(), None, None),
+        ("pad", dict(), [0, 2], [0, 3]),          # sample 1 has 2 padded bins, shifted stamps
+        ("sep", dict(sep=True), [0, 2], None),
+        ("causal", dict(causal=True), [0, 2], None),
+        ("deep", dict(n_enc=2, n_dec=2), None, None),
+    ]
+    for vname, kw, pad, shift in variants:
+        mcfg = tiny_model_cfg(**kw)
+        model = build_model(mcfg, n_ap, n_beh, seed=7)
+        model.train()
+        sd = {k: v.clone() for k, v in model.state_dict().items()}
+        for k, v in sd.items():
+            arrs[f"{vname}/sd/{k}"] = npify(v)
+        batch = synth_batch(B, T, n_ap, n_beh, seed=3, pad=pad, ts_shift=shift)
+        for k, v in batch.items():
+            arrs[f"{vname}/batch/{k}"] = npify(v)
+        for obj in ("encoding", "decoding", "token_masking"):
+            caps = {}
+            hooks = []
+
+            def cap(name):
+                def fn(_m, _i, o):
+                    caps[name] = o.detach().clone()
+                return fn
+            def cap2(name):
+                def fn(_m, _i, o):
+                    caps[name + "_x"], caps[name + "_emb"] = o[0].detach().clone(), o[1].detach().clone()
+                return fn
+            for mod in ("ap", "behavior"):
+                hooks.append(model.encoder_embeddings[mod].embedder.register_forward_hook(cap2(f"enc_embed/{mod}")))
+                hooks.append(model.decoder_embeddings[mod].embedder.register_forward_hook(cap2(f"dec_embed/{mod}")))
+            hooks.append(model.encoder_norm.register_forward_hook(cap("enc_out")))
+            hooks.append(model.decoder_proj_context.register_forward_hook(cap("ctx_proj")))
+            hooks.append(model.decoder_norm.register_forward_hook(cap("dec_out")))
+            model.zero_grad(set_to_none=True)
+            torch.manual_seed(11)      # masker stream for token_masking
+            md = make_mod_dict(batch, obj)
+            out = model(md)
+            out.loss.backward()
+            for h in hooks:
+                h.remove()
+            p = f"{vname}/{obj}"
+            arrs[f"{p}/loss"] = npify(out.loss)
+            for mod in ("ap", "behavior"):
+                arrs[f"{p}/mod_loss/{mod}"] = npify(out.mod_loss[mod])
+                arrs[f"{p}/n/{mod}"] = npify(out.mod_n_examples[mod])
+                arrs[f"{p}/preds/{mod}"] = npify(out.mod_preds[mod])
+                arrs[f"{p}/mask/{mod}"] = npify(md[mod]["inputs_mask"])
+            for k, v in caps.items():
+                arrs[f"{p}/{k}"] = npify(v)
+            for k, prm in model.named_parameters():
+                arrs[f"{p}/grad/{k}"] = npify(prm.grad)
+            meta["cases"].append(p)
+    arrs["meta"] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    save_npz("tiny_fwd_bwd.npz", **arrs)
+
+
+def default_batch():
+    return synth_batch(16, 100, 668, 2, seed=0)
+
+
+def fx_default_scalars():
+    cfg = ref_config()
+    model = build_model(cfg.model, 668, 2, seed=42)
+    model.eval()
+    batch = default_batch()
+    res = {}
+    for obj in ("encoding", "decoding", "token_masking"):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(1)
+        out = model(make_mod_dict(batch, obj))
+        out.loss.backward()
+        res[obj] = dict(
+            loss=float(out.loss),
+            mod_loss={m: float(v) for m, v in out.mod_loss.items()},
+            n={m: int(v) for m, v in out.mod_n_examples.items()},
+            pred_abssum={m: float(v.double().abs().sum()) for m, v in out.mod_preds.items()},
+            grad_norm={k: float(p.grad.double().norm()) for k, p in model.named_parameters()})
+        print("   ", obj, res[obj]["loss"], res[obj]["n"])
+    save_json("default_scalars.json", res)
+
+
+def fx_masker_bits():
+    base = plain(ref_config()["model"]["masker"])
+    arrs, cases = {}, []
+    cid = 0
+    for seed in (0, 5):
+        for ratio in (0.1, 0.3):
+            for expand_prob, max_ts in ((0.0, 1), (1.0, 3)):
+                mc = dict(base, ratio=ratio, expand_prob=expand_prob, max_timespan=max_ts)
+                mk = Masker(DictConfig(mc))
+                mk.train()
+                torch.manual_seed(seed)
+                g = torch.Generator().manual_seed(100 + seed)
+                ap = torch.poisson(torch.full((4, 20, 9), 0.3), generator=g)
+                bh = torch.randn(4, 20, 2, generator=g)
+                regions = np.full((4, 9), "XX")
+                _, m_ap = mk(ap.clone(), regions)          # first call (ap)
+                _, m_bh = mk(bh.clone(), None)             # second call (behaviour)
+                after = torch.rand(3)                      # pins the generator state afterwards
+                arrs[f"c{cid}/ap"] = npify(ap)
+                arrs[f"c{cid}/bh"] = npify(bh)
+                arrs[f"c{cid}/mask_ap"] = npify(m_ap)
+                arrs[f"c{cid}/mask_bh"] = npify(m_bh)
+                arrs[f"c{cid}/after"] = npify(after)
+                cases.append(dict(id=cid, seed=seed, cfg=mc))
+                cid += 1
+    # early-outs (masker.py:62-69)
+    mk = Masker(DictConfig(dict(base, ratio=0)))
+    x = torch.ones(2, 3, 4)
+    _, z = mk(x.clone(), None)
+    arrs["zero_ratio_mask"] = npify(z)
+    arrs["meta"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    save_npz("masker_bits.npz", **arrs)
+
+
+def fx_mask_index_ops():
+    """forward_mask_encoder / forward_mask_decoder on hand-made masks (mm.py:141-194)."""
+    B, T, H = 3, 6, 4
+    arrs, cases = {}, []
+    g = torch.Generator().manual_seed(9)
+    hand = {
+        "none": torch.zeros(B, T, dtype=torch.int64),
+        "one": torch.zeros(B, T, dtype=torch.int64),
+        "many": (torch.rand(B, T, generator=g) < 0.5).to(torch.int64),
+        "all": torch.ones(B, T, dtype=torch.int64),
+    }
+    hand["one"][0, 2] = 1
+    hand["one"][1, 4] = 1
+    attn = torch.ones(B, T, dtype=torch.int64)
+    attn[1, 4:] = 0
+    attn[2, 5:] = 0
+    for sep in (False, True):
+        for causal in (False, True):
+            model = build_model(tiny_model_cfg(H=H, heads=2, inter=8, max_F=T, sep=sep, causal=causal),
+                                5, 2, seed=1)
+            for name, mk in hand.items():
+                md = {}
+                for i, mod in enumerate(("ap", "behavior")):
+                    msk = (mk if mod == "ap" else mk.flip(1)) & attn
+                    md[mod] = dict(x=torch.randn(B, T, H, generator=g), emb=torch.randn(B, T, H, generator=g),
+                                   gt=torch.zeros(B, T, 1), inputs_mask=msk, targets_mask=msk,
+                                   encoder_attn_mask=attn, decoder_attn_mask=attn)
+                key = f"sep{int(sep)}_causal{int(causal)}/{name}"
+                for mod in md:
+                    arrs[f"{key}/in_x/{mod}"] = npify(md[mod]["x"])
+                    arrs[f"{key}/in_mask/{mod}"] = npify(md[mod]["inputs_mask"])
+                et, ee, em, eam, emm = model.forward_mask_encoder(md)
+                dt, _, de, dm, dam, dmm = model.forward_mask_decoder(md)
+                arrs[f"{key}/enc_tokens"] = npify(et)
+                arrs[f"{key}/enc_mask"] = npify(em)
+                arrs[f"{key}/enc_attn_mask"] = npify(eam)
+                arrs[f"{key}/enc_mod_mask"] = npify(emm)
+                arrs[f"{key}/dec_tokens"] = npify(dt)
+                arrs[f"{key}/dec_attn_mask"] = npify(dam.to(torch.int64))
+                arrs[f"{key}/dec_mod_mask"] = npify(dmm)
+                cases.append(key)
+    arrs["attn"] = npify(attn)
+    arrs["meta"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    save_npz("mask_index_ops.npz", **arrs)
+
+
+def make_opt(model, total_steps, lr=1e-4, wd=0.01, eps=1e-8):
+    from torch.optim.lr_scheduler import OneCycleLR
+    opt = torch.optim.AdamW(model.parameters(), lr=lr, weight_decay=wd, eps=eps)
+    sch = OneCycleLR(optimizer=opt, total_steps=total_steps, max_lr=lr, pct_start=0.15, div_factor=10)
+    return opt, sch
+
+
+def fx_sched_adamw():
+    lin = torch.nn.Linear(2, 2)
+    opt, sch = make_opt(lin, 1000)
+    lrs, b1s = [], []
+    for _ in range(1000):
+        lrs.append(opt.param_groups[0]["lr"])
+        b1s.append(opt.param_groups[0]["betas"][0])
+        opt.step()
+        sch.step()
+    arrs = dict(lr=np.asarray(lrs, dtype=np.float64), beta1=np.asarray(b1s, dtype=np.float64))
+    # 5-step AdamW trajectory on the tiny model, encoding objective, total_steps=20
+    B, T, n_ap, n_beh = 2, 8, 12, 2
+    model = build_model(tiny_model_cfg(), n_ap, n_beh, seed=7)
+    model.train()
+    opt, sch = make_opt(model, 20)
+    for step in range(5):
+        batch = synth_batch(B, T, n_ap, n_beh, seed=step)
+        out = model(make_mod_dict(batch, "encoding"))
+        out.loss.backward()
+        opt.step()
+        sch.step()
+        opt.zero_grad()
+        arrs[f"traj/loss{step}"] = npify(out.loss)
+    for k, v in model.state_dict().items():
+        arrs[f"traj/final/{k}"] = npify(v)
+    save_npz("sched_adamw.npz", **arrs)
+
+
+def run_curve(model, steps, B, T, n_ap, n_beh, total_steps):
+    opt, sch = make_opt(model, total_steps)
+    model.train()
+    random.seed(42)
+    torch.manual_seed(1234)
+    losses, objs = [], []
+    for step in range(steps):
+        obj = random.sample(["encoding", "decoding", "token_masking"], 1)[0]
+        batch = synth_batch(B, T, n_ap, n_beh, seed=step)
+        out = model(make_mod_dict(batch, obj))
+        out.loss.backward()
+        opt.step()
+        sch.step()
+        opt.zero_grad()
+        losses.append(float(out.loss))
+        objs.append(obj)
+    return losses, objs
+
+
+def fx_loss_curve():
+    res = {}
+    model = build_model(tiny_model_cfg(), 12, 2, seed=7)
+    l, o = run_curve(model, 50, 2, 8, 12, 2, total_steps=50)
+    res["tiny"] = dict(loss=l, objective=o, model_seed=7, B=2, T=8, n_ap=12, n_beh=2, total_steps=50)
+    cfg = plain(ref_config()["model"])
+    for side in ("encoder", "decoder"):
+        cfg[side]["embedder"]["dropout"] = 0.0
+        cfg[side]["transformer"]["dropout"] = 0.0
+    model = build_model(DictConfig(cfg), 668, 2, seed=42)
+    l, o = run_curve(model, 30, 16, 100, 668, 2, total_steps=1000)
+    res["default"] = dict(loss=l, objective=o, model_seed=42, B=16, T=100, n_ap=668, n_beh=2,
+                          total_steps=1000)
+    print("    default curve:", l[:3], "...", l[-1])
+    save_json("loss_curve.json", res)
+
+
+def fx_trainer_io():
+    """The reference trainer on 3 synthetic batches (wandb / torcheval stubbed)."""
+    import transformers  # noqa: F401  (import before stubbing)
+    wb = types.ModuleType("wandb")
+    wb.log = lambda *a, **k: None
+    wb.Image = lambda x: x
+    sys.modules.setdefault("wandb", wb)
+    te = types.ModuleType("torcheval")
+    tem = types.ModuleType("torcheval.metrics")
+
+    class R2Score:
+        def reset(self):
+            self.p, self.t = [], []
+
+        def to(self, d):
+            return self
+
+        def update(self, p, t):
+            self.p.append(p)
+            self.t.append(t)
+
+        def compute(self):
+            p, t = torch.cat(self.p), torch.cat(self.t)
+            return 1 - ((t - p) ** 2).sum() / ((t - t.mean()) ** 2).sum()
+    tem.R2Score = R2Score
+    te.metrics = tem
+    sys.modules.setdefault("torcheval", te)
+    sys.modules.setdefault("torcheval.metrics", tem)
+    import matplotlib
+    matplotlib.use("Agg")
+    from trainer.make import make_multimodal_trainer
+
+    B, T, n_ap, n_beh = 4, 8, 12, 2
+    cfg = ref_config()
+    model = build_model(tiny_model_cfg(), n_ap, n_beh, seed=7)
+
+    def loader(seed0):
+        out = []
+        for i in range(3):
+            b = synth_batch(B, T, n_ap, n_beh, seed=seed0 + i)
+            b["eid"] = ["synthetic"] * B
+            b["neuron_regions"] = [["XX"] * B for _ in range(n_ap)]
+            out.append(b)
+        return out
+    opt, sch = make_opt(model, 100)
+
+    class Acc:
+        device = torch.device("cpu")
+    tr = make_multimodal_trainer(model=model, train_dataloader=loader(0), eval_dataloader=loader(50),
+                                 optimizer=opt, log_dir="/tmp", accelerator=Acc(), lr_scheduler=sch,
+                                 avail_mod=["ap", "behavior"],
+                                 modal_filter=dict(input=["ap", "behavior"], output=["ap", "behavior"]),
+                                 mixed_training=True, config=cfg, num_neurons=[n_ap])
+    random.seed(42)
+    torch.manual_seed(99)
+    st = random.getstate()
+    objs = [random.sample(["encoding", "decoding", "token_masking"], 1)[0] for _ in range(6)]
+    random.setstate(st)
+    tr_res = tr.train_epoch(0)
+    ev = tr.eval_epoch()
+    save_json("trainer_io.json", dict(
+        B=B, T=T, n_ap=n_ap, n_beh=n_beh, model_seed=7, objectives=objs,
+        train_loss=float(tr_res["train_loss"]), eval_loss=float(ev["eval_loss"]),
+        eval_keys=sorted(ev.keys()),
+        eval_gt_shapes={m: list(ev["eval_gt"][0][m].shape) for m in ev["eval_gt"][0]},
+        eval_preds_shapes={m: list(ev["eval_preds"][0][m].shape) for m in ev["eval_preds"][0]},
+        eval_preds_abssum={m: float(ev["eval_preds"][0][m].double().abs().sum()) for m in ev["eval_preds"][0]},
+        eval_trial_avg_r2=float(ev["eval_trial_avg_r2"])))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    only = set(sys.argv[1:])
+    for name, fn in [("init_order", fx_init_order), ("tiny_fwd_bwd", fx_tiny_fwd_bwd),
+                     ("default_scalars", fx_default_scalars), ("masker_bits", fx_masker_bits),
+                     ("mask_index_ops", fx_mask_index_ops), ("sched_adamw", fx_sched_adamw),
+                     ("loss_curve", fx_loss_curve), ("trainer_io", fx_trainer_io)]:
+        if only and name not in only:
+            continue
+        print(f"[{name}]")
+        fn()
+
+
+if __name__ == "__main__":
+    main()
