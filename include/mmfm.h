@@ -1,0 +1,201 @@
+/* mmfm.h — C-ABI of libmmfm_hip.so: hand-written HIP (gfx950 / CDNA4) kernels for the
+ * masked-pretraining hot path of yzhang511/multi_modal_foundation_model.
+ *
+ * The reference has no FFI: the path sits behind Python classes.  Each entry
+ * point below names the reference site (file:line under /root/reference/src) whose device work
+ * it replaces.  INTEGRATION.md shows the ctypes stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - every entry returns 0 on success, a hipError_t (>0) or -1 (argument check) otherwise;
+ *    the message is available through mmfm_last_error() (thread-local);
+ *  - all buffers are caller-allocated DEVICE pointers; the library never allocates, frees,
+ *    retains or synchronises (every launch function is hipGraph-capturable);
+ *  - `stream` is a hipStream_t passed as void*;
+ *  - dtype: 0 = f32 storage (parity mode), 1 = bf16 storage with fp32 accumulate/statistics;
+ *  - row-major everywhere; "ld" = leading dimension in elements.
+ */
+#ifndef MMFM_H
+#define MMFM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MMFM_VERSION 100
+#define MMFM_F32 0
+#define MMFM_BF16 1
+
+typedef void* mmfm_stream;
+
+/* Counter-based dropout: keep(idx) = f(state[0], state[1], site, idx); state = 2 x uint32 in
+ * DEVICE memory (so graph replays see new masks after mmfm_rng_advance).  p <= 0 disables.
+ * Replaces nn.Dropout / SDPA dropout_p (mm_utils.py:52,111,114; encoder_embeddings.py:61). */
+typedef struct {
+    const void* state;
+    uint32_t site;
+    float p;
+} mmfm_dropout;
+
+int mmfm_version(void);
+const char* mmfm_last_error(void);
+/* 0 iff `device` is a gfx950 part. */
+int mmfm_device_check(int device);
+/* state[0]=lo32(mix(seed)), state[1]=step counter start */
+int mmfm_rng_seed(void* state, uint64_t seed, mmfm_stream stream);
+int mmfm_rng_advance(void* state, mmfm_stream stream);
+
+/* ---------------------------------------------------------------------------------- GEMM
+ * C[m][n] = epi( sum_k A(m,k) * B(k,n) ).  Replaces every nn.Linear forward/backward on the
+ * path (mm_utils.py:46-52,88-95,107-114; encoder_embeddings.py:28-30,50-54;
+ * decoder_embeddings.py:83,107; mm.py:74,292) and their autograd.
+ *   a_kcontig: 1 -> A(m,k) = A[m*lda + k];  0 -> A(m,k) = A[k*lda + m]
+ *   b_kcontig: 1 -> B(k,n) = B[n*ldb + k] (an nn.Linear weight [N,K]);  0 -> B(k,n) = B[k*ldb + n]
+ *   splits > 1: split-K; split z covers k in [z*kchunk, (z+1)*kchunk) and writes its raw fp32
+ *               partial tile to C + z*slab_stride (no epilogue); reduce with mmfm_reduce_slabs.
+ * epilogue (splits == 1), in this order:
+ *   v = acc + bias[n]; pre_out[m*ldc+n] = v;
+ *   act 1: v = gelu_erf(v)           act 2: v = softsign(v) * act_scale          (forward)
+ *   act 3: v *= gelu_erf'(gradmul_pre[m*ldc+n])   act 4: v *= softsign'(gradmul_pre[..]) * act_scale
+ *          (backward through the activation whose pre-activation the forward stored via pre_out);
+ *   v = dropout(v) (counter m*N+n);  v += residual[m*ldr+n];  C[m*ldc+n] = v
+ */
+typedef struct {
+    int dtype;       /* storage of A, B, pre_out, gradmul_pre, residual and (unless c_f32) C */
+    int c_f32;       /* 1: C is fp32 regardless of dtype */
+    const void* A;
+    const void* B;
+    void* C;
+    int M, N, K;
+    int lda, ldb, ldc;
+    int a_kcontig, b_kcontig;
+    int splits, kchunk;
+    int64_t slab_stride;
+    const float* bias;
+    void* pre_out;
+    int act;
+    float act_scale;
+    const void* gradmul_pre;
+    mmfm_dropout drop;
+    const void* residual;
+    int ldr;
+} mmfm_gemm_desc;
+int mmfm_gemm(const mmfm_gemm_desc* d, mmfm_stream stream);
+
+/* dst[i] (+)= sum_s src[s*slab_stride + i], fp32, deterministic order. */
+int mmfm_reduce_slabs(float* dst, const float* src, int64_t n, int nslabs, int64_t slab_stride,
+                      int accumulate, mmfm_stream stream);
+/* out[n] (+)= sum_r x[r*ld + n]   (bias gradients).  workspace >= mmfm_colsum_workspace bytes. */
+int64_t mmfm_colsum_workspace(int64_t R, int N);
+int mmfm_colsum(int dtype, const void* x, int64_t R, int N, int ld, float* out, int accumulate,
+                void* workspace, int64_t workspace_bytes, mmfm_stream stream);
+
+/* ---------------------------------------------------------------------------------- LayerNorm
+ * nn.LayerNorm(H), eps 1e-5, affine: encoder_embeddings.py:98,100; decoder_embeddings.py:118-126;
+ * mm.py:72,77.  One wavefront per row, fp32 statistics.
+ * destitch_T > 0: output row for input row r=(b,l) is (l/T)*(B*T) + b*T + l%T, i.e. the final
+ * decoder_norm writes per-modality contiguous [M][B*T][H] blocks (the boolean gather of
+ * decoder_embeddings.py:105 becomes a plain slice); the backward reads dy the same way. */
+int mmfm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
+                       float* mean, float* rstd, int64_t R, int H, float eps,
+                       int destitch_L, int destitch_T, mmfm_stream stream);
+int64_t mmfm_layernorm_bwd_workspace(int64_t R, int H);
+/* dx = dres + LN'(dy);  dgamma/dbeta (+)= column sums.  dres may be NULL; dx may alias dres. */
+int mmfm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd,
+                       const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
+                       int accumulate, int64_t R, int H, int destitch_L, int destitch_T,
+                       void* workspace, int64_t workspace_bytes, mmfm_stream stream);
+
+/* ---------------------------------------------------------------------------------- attention
+ * F.scaled_dot_product_attention with the reference's masks (mm_utils.py:105-111,143-149;
+ * mm.py:152-158,178-194) without materialising [B,h,L,L]:
+ *   allowed(b,q,k) = (DIAG && q==k) | (CAUSAL ? k<=q : keypad[b][k]) | (SEP && mod_id[q]!=mod_id[k])
+ * q/k/v/o are [B, L, heads*dh] views with row strides ldq/ldk/ldv/ldo (so a fused QKV buffer
+ * works); lse is [B, heads, Lq] fp32.  drop_p acts on the probabilities, drop_o on the output
+ * (the nn.Dropout in front of out_proj, mm_utils.py:114). */
+#define MMFM_ATTN_DIAG 1
+#define MMFM_ATTN_CAUSAL 2
+#define MMFM_ATTN_SEP 4
+typedef struct {
+    int dtype;
+    int B, heads, Lq, Lk, dh;
+    const void* q; const void* k; const void* v;
+    int ldq, ldk, ldv;
+    void* o; int ldo;            /* fwd: output (after drop_o).  bwd: the forward's output */
+    float* lse;
+    const uint8_t* keypad;       /* [B][Lk] */
+    const uint8_t* mod_id;       /* [max(Lq,Lk)] or NULL */
+    int flags;
+    float scale;
+    mmfm_dropout drop_p, drop_o;
+    /* backward only */
+    const void* d_o; int lddo;   /* grad wrt the out_proj input (i.e. AFTER drop_o) */
+    void* dq; void* dk; void* dv;
+    int lddq, lddk, lddv;
+} mmfm_attn_desc;
+int mmfm_attn_fwd(const mmfm_attn_desc* d, mmfm_stream stream);
+int mmfm_attn_bwd(const mmfm_attn_desc* d, mmfm_stream stream);
+
+/* ---------------------------------------------------------------------------------- masks / stitch
+ * mm.py:245-275 (mask = eval_mask[:,:,0] & attn_mask), :102 (mod_mask), :145,167 (sample-0 ids),
+ * :229-233 (n_examples).  For modality m: mask_src[m] is int64 with element (b,t) at
+ * mask_src[m][(b*T+t)*mask_stride[m]]; attn is int64 [B][T].
+ * Outputs: tokmask u8 [B][M*T], keypad u8 [B][M*T], keep0 u8 [M*T] (0 where sample 0 is masked),
+ * mod_id u8 [M*T], count int64 [M] = channels[m] * sum(tokmask of modality m).  Bit-exact. */
+int mmfm_mask_prep(int B, int T, int M, const int64_t* const* mask_src, const int64_t* mask_stride,
+                   const int64_t* attn, const int64_t* channels, uint8_t* tokmask, uint8_t* keypad,
+                   uint8_t* keep0, uint8_t* mod_id, int64_t* count, mmfm_stream stream);
+
+/* encoder_embeddings.py:56-61 + mm.py:90-110,143-149,289 (and the decoder twins):
+ *   emb[b, m*T+t] = mod_emb[mod_row] + pos_emb[ts[b][t]]
+ *   x  [b, m*T+t] = keep0[m*T+t] * tok[b*T+t] + emb[...]
+ * called once per modality m; tok is [B*T][H]; x/emb are [B][L][H]; emb may be NULL; pos_emb has
+ * max_F rows (time stamps are clamped into [0, max_F) for memory safety). */
+int mmfm_stitch_fwd(int dtype, const void* tok, const float* mod_emb_row, const float* pos_emb,
+                    const int64_t* ts, const uint8_t* keep0, void* x, void* emb,
+                    int B, int T, int L, int m, int H, int max_F, mmfm_stream stream);
+/* autograd of the above for one modality: d_tok[b*T+t] = keep0 * dropout'(dx[b, m*T+t]);
+ * d_mod_row (+)= sum_{b,t} (dx + dextra);  d_pos[ts[b][t]] (+)= dx + dextra  (dextra may be NULL:
+ * it is d_context -> encoder_emb, mm.py:292).  Deterministic two-stage scatter (no atomics). */
+int64_t mmfm_stitch_bwd_workspace(int B, int T, int H, int max_F);
+int mmfm_stitch_bwd(int dtype, const void* dx, const void* dextra, const int64_t* ts, const uint8_t* keep0,
+                    mmfm_dropout drop, void* d_tok, float* d_mod_row, float* d_pos, int accumulate,
+                    int B, int T, int L, int m, int H, int max_F,
+                    void* workspace, int64_t workspace_bytes, mmfm_stream stream);
+
+/* ---------------------------------------------------------------------------------- masked loss
+ * mm.py:79-82,217-239.  kind 0: PoissonNLL(log_input) exp(p) - t*p;  kind 1: MSE (p-t)^2.
+ * pred [R][N] (dtype), target [R][N] fp32, rowmask u8 [R] (element (b,t) at rowmask[b*mask_ld + t]).
+ * fwd writes the modality's masked SUM to loss_sum[0] (fp32, deterministic two-stage). */
+int64_t mmfm_masked_loss_workspace(int64_t R, int N);
+int mmfm_masked_loss_fwd(int dtype, int kind, const void* pred, const float* target, const uint8_t* rowmask,
+                         int mask_ld, int T, int64_t R, int N, float* loss_sum,
+                         void* workspace, int64_t workspace_bytes, mmfm_stream stream);
+/* loss = sum_m loss_sum[m] / sum_m count[m]   (0/0 -> NaN like the reference);  inv_n = 1/sum count */
+int mmfm_loss_finalize(const float* loss_sum, const int64_t* count, int M, float* loss, float* inv_n,
+                       mmfm_stream stream);
+/* dpred = grad_out[0] * inv_n[0] * rowmask * d/dp loss_elem */
+int mmfm_masked_loss_bwd(int dtype, int kind, const void* pred, const float* target, const uint8_t* rowmask,
+                         int mask_ld, int T, int64_t R, int N, const float* grad_out, const float* inv_n,
+                         void* dpred, mmfm_stream stream);
+
+/* ---------------------------------------------------------------------------------- elementwise
+ * dst = dropout(src) with counter row*N + col (the backward of a dropout whose forward was fused
+ * into a GEMM epilogue). */
+int mmfm_dropout_apply(int dtype, const void* src, void* dst, int64_t R, int N, mmfm_dropout drop,
+                       mmfm_stream stream);
+int mmfm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, mmfm_stream stream);
+
+/* ---------------------------------------------------------------------------------- optimiser
+ * torch.optim.AdamW single step over a flat fp32 parameter range (train_multi_modal.py:197-202,
+ * trainer/base.py:196).  hyper is a DEVICE array of 8 floats the host computes in double:
+ *   [1-lr*wd, 1-beta1, beta2, 1-beta2, lr/bias_correction1, sqrt(bias_correction2), eps, grad_scale]
+ * (OneCycleLR rewrites lr AND beta1 every step, so they are data, not launch constants; g is
+ * multiplied by grad_scale first, e.g. 1/world_size after a SUM all-reduce).
+ * If p_bf16 != NULL the updated parameters are also written as bf16 (throughput mode weights). */
+int mmfm_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
+                    const float* hyper, mmfm_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,107 @@
+"""ctypes binding of libmmfm_hip.so (the C-ABI declared in include/mmfm.h).
+
+There is NO fallback: if the shared library is missing or a call fails this raises.  Build with
+``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C multi_modal_foundation_model_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmmfm_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmfm.h")
+
+F32, BF16 = 0, 1
+ATTN_DIAG, ATTN_CAUSAL, ATTN_SEP = 1, 2, 4
+ACT_NONE, ACT_GELU, ACT_SOFTSIGN, ACT_GELU_GRAD, ACT_SOFTSIGN_GRAD = 0, 1, 2, 3, 4
+
+
+class MmfmError(RuntimeError):
+    pass
+
+
+class Dropout(C.Structure):
+    _fields_ = [("state", C.c_void_p), ("site", C.c_uint32), ("p", C.c_float)]
+
+
+NO_DROP = Dropout(None, 0, 0.0)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("c_f32", C.c_int), ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("lda", C.c_int), ("ldb", C.c_int), ("ldc", C.c_int),
+                ("a_kcontig", C.c_int), ("b_kcontig", C.c_int), ("splits", C.c_int), ("kchunk", C.c_int),
+                ("slab_stride", C.c_int64), ("bias", C.c_void_p), ("pre_out", C.c_void_p), ("act", C.c_int),
+                ("act_scale", C.c_float), ("gradmul_pre", C.c_void_p), ("drop", Dropout), ("residual", C.c_void_p),
+                ("ldr", C.c_int)]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("B", C.c_int), ("heads", C.c_int), ("Lq", C.c_int), ("Lk", C.c_int), ("dh", C.c_int),
+                ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("ldq", C.c_int), ("ldk", C.c_int),
+                ("ldv", C.c_int), ("o", C.c_void_p), ("ldo", C.c_int), ("lse", C.c_void_p), ("keypad", C.c_void_p),
+                ("mod_id", C.c_void_p), ("flags", C.c_int), ("scale", C.c_float), ("drop_p", Dropout),
+                ("drop_o", Dropout), ("d_o", C.c_void_p), ("lddo", C.c_int), ("dq", C.c_void_p), ("dk", C.c_void_p),
+                ("dv", C.c_void_p), ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int)]
+
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_PROTOS = {
+    "mmfm_version": (C.c_int, []),
+    "mmfm_last_error": (C.c_char_p, []),
+    "mmfm_device_check": (C.c_int, [_i]),
+    "mmfm_rng_seed": (C.c_int, [_vp, C.c_uint64, _vp]),
+    "mmfm_rng_advance": (C.c_int, [_vp, _vp]),
+    "mmfm_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "mmfm_reduce_slabs": (C.c_int, [_vp, _vp, _i64, _i, _i64, _i, _vp]),
+    "mmfm_colsum_workspace": (C.c_int64, [_i64, _i]),
+    "mmfm_colsum": (C.c_int, [_i, _vp, _i64, _i, _i, _vp, _i, _vp, _i64, _vp]),
+    "mmfm_layernorm_fwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp]),
+    "mmfm_layernorm_bwd_workspace": (C.c_int64, [_i64, _i]),
+    "mmfm_layernorm_bwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _i64, _vp]),
+    "mmfm_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
+    "mmfm_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
+    "mmfm_mask_prep": (C.c_int, [_i, _i, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mmfm_stitch_fwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "mmfm_stitch_bwd_workspace": (C.c_int64, [_i, _i, _i, _i]),
+    "mmfm_stitch_bwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, Dropout, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "mmfm_masked_loss_workspace": (C.c_int64, [_i64, _i]),
+    "mmfm_masked_loss_fwd": (C.c_int, [_i, _i, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _i64, _vp]),
+    "mmfm_loss_finalize": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp]),
+    "mmfm_masked_loss_bwd": (C.c_int, [_i, _i, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp]),
+    "mmfm_dropout_apply": (C.c_int, [_i, _vp, _vp, _i64, _i, Dropout, _vp]),
+    "mmfm_cast_f32_to_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "mmfm_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Every function the C header declares (used by the CPU export test)."""
+    with open(HEADER_PATH) as f:
+        src = f.read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mmfm_[a-z0-9_]+)\s*\(", src)))
+
+
+def lib():
+    """The loaded library with typed prototypes.  Raises ImportError if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: the HIP extension is not built and there is no CPU "
+                              "fallback.  Run `python -c 'import __graft_entry__ as g; g.build()'`.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise MmfmError(f"{what} failed (code {rc}): {lib().mmfm_last_error().decode(errors='replace')}")

@@ -1,0 +1,481 @@
+// Masked scaled-dot-product attention, forward and backward (mmfm_attn_fwd / mmfm_attn_bwd).
+//
+// fp32 parity path on v_mfma_f32_32x32x2_f32.  One workgroup (4 wavefronts) per (batch, head);
+// the head's K and V (L <= a few hundred tokens, dh <= 64) stay in LDS for the whole workgroup.
+// The [B,h,L,L] mask of the reference is never materialised: keypad bytes + flags.
+//
+// Forward (flash style, online softmax): each wave owns 32-query tiles and walks 32-key tiles.
+//   S^T = K Q^T is computed with the KEY on the MFMA row and the QUERY on the lane, so the
+//   softmax statistics of a query are lane-local (one __shfl_xor(32) joins the two half-waves)
+//   and the probabilities, still in accumulator registers, are directly the B operand of
+//   O^T += V^T P^T (k-pairing (s&3)+8(s>>2) [+4 for the upper half]: no LDS round trip).
+// Backward: recompute P from Q, K and the saved LSE.  Phase A: a wave owns a key tile and keeps
+//   dK^T, dV^T in accumulators over all query tiles.  Phase B: a wave owns a query tile and keeps
+//   dQ^T.  No atomics: results are bitwise reproducible.
+#include "common.h"
+#include <algorithm>
+#include <mutex>
+#include <unordered_map>
+
+namespace {
+
+__device__ __forceinline__ int mrow(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
+
+struct MaskCtx {
+    const uint8_t* kpad;   // LDS [LkP]
+    const uint8_t* modq;   // LDS or null
+    const uint8_t* modk;
+    int flags;
+    __device__ __forceinline__ bool allowed(int q, int k) const {
+        bool a = (flags & MMFM_ATTN_CAUSAL) ? (k <= q) : (kpad[k] != 0);
+        if ((flags & MMFM_ATTN_DIAG) && q == k) a = true;
+        if ((flags & MMFM_ATTN_SEP) && modq[q] != modk[k]) a = true;
+        return a;
+    }
+};
+
+// cooperative load of rows [0,L) x DH floats of one head into LDS with row stride LD; rows [L,LP) zeroed
+template <typename T, int DH>
+__device__ __forceinline__ void load_head(float* __restrict__ dst, int LD, const T* __restrict__ src, int ld, int L, int LP,
+                                          int t, int nthreads) {
+    constexpr int C4 = DH / 4;
+    for (int idx = t; idx < LP * C4; idx += nthreads) {
+        const int row = idx / C4, c = idx % C4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < L) v = io<T>::ld4(src + (size_t)row * ld + 4 * c);
+        float* d = dst + row * LD + 4 * c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+}
+
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ============================================================================ forward
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const mmfm_attn_desc d) {
+    constexpr int DT = (DH + 31) / 32;      // 32-row tiles of the head dim
+    constexpr int LD = DH + 1;              // K / Q LDS row stride (odd: conflict-free column reads)
+    constexpr int DVL = DT * 32;            // V LDS row stride (zero padded to the MFMA tile)
+    constexpr int SLD = DVL + 1;            // per-wave scratch stride
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kh = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int Lq = d.Lq, Lk = d.Lk;
+    const int LkP = (Lk + 31) & ~31;
+    const int Lmx = max(Lq, Lk);
+    float* Ks = smem;                                  // [LkP][LD]
+    float* Vs = Ks + LkP * LD;                         // [LkP][DVL]
+    float* Sc = Vs + LkP * DVL;                        // [4][32][SLD]
+    uint8_t* kpad = reinterpret_cast<uint8_t*>(Sc + 4 * 32 * SLD);   // [LkP]
+    uint8_t* modl = kpad + LkP;                                      // [Lmx] (SEP only)
+
+    const T* qg = reinterpret_cast<const T*>(d.q) + (size_t)b * Lq * d.ldq + h * DH;
+    const T* kg = reinterpret_cast<const T*>(d.k) + (size_t)b * Lk * d.ldk + h * DH;
+    const T* vg = reinterpret_cast<const T*>(d.v) + (size_t)b * Lk * d.ldv + h * DH;
+    T* og = reinterpret_cast<T*>(d.o) + (size_t)b * Lq * d.ldo + h * DH;
+
+    load_head<T, DH>(Ks, LD, kg, d.ldk, Lk, LkP, t, 256);
+    {   // V: float4 rows, zero pad columns [DH, DVL) and rows [Lk, LkP)
+        constexpr int C4 = DVL / 4;
+        for (int idx = t; idx < LkP * C4; idx += 256) {
+            const int row = idx / C4, c = idx % C4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < Lk && 4 * c < DH) v = io<T>::ld4(vg + (size_t)row * d.ldv + 4 * c);
+            *reinterpret_cast<float4*>(Vs + row * DVL + 4 * c) = v;
+        }
+    }
+    for (int i = t; i < LkP; i += 256) kpad[i] = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
+    if (d.flags & MMFM_ATTN_SEP)
+        for (int i = t; i < Lmx; i += 256) modl[i] = d.mod_id[i];
+    __syncthreads();
+
+    MaskCtx mk{kpad, modl, modl, d.flags};
+    const Drop dp = drop_init(d.drop_p), dout = drop_init(d.drop_o);
+    float* sc = Sc + wave * 32 * SLD;
+    const int nqt = (Lq + 31) / 32, nkt = LkP / 32;
+
+    for (int qt = wave; qt < nqt; qt += 4) {
+        const int q0 = qt * 32;
+        // ---- Q tile -> scratch (coalesced) -> operand registers, pre-scaled
+        wave_lds_fence();
+        {
+            constexpr int C4 = DH / 4;
+            for (int idx = lane; idx < 32 * C4; idx += 64) {
+                const int row = idx / C4, c = idx % C4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (q0 + row < Lq) v = io<T>::ld4(qg + (size_t)(q0 + row) * d.ldq + 4 * c);
+                float* p = sc + row * SLD + 4 * c;
+                p[0] = v.x; p[1] = v.y; p[2] = v.z; p[3] = v.w;
+            }
+        }
+        wave_lds_fence();
+        float qreg[DH / 2];
+#pragma unroll
+        for (int s = 0; s < DH / 2; ++s) qreg[s] = sc[l31 * SLD + 2 * s + kh] * d.scale;
+
+        const int q = q0 + l31;
+        float m_run = -INFINITY, l_run = 0.f;
+        f32x16 acc[DT];
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x16 st;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            const float* ka = Ks + (kt * 32 + l31) * LD + kh;
+#pragma unroll
+            for (int s = 0; s < DH / 2; ++s) st = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * s], qreg[s], st, 0, 0, 0);
+            float mx = -INFINITY;
+            bool ok[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + mrow(r, kh);
+                ok[r] = (key < Lk) && (q < Lq) && mk.allowed(q, key);
+                if (ok[r]) mx = fmaxf(mx, st[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            if (__all(m_new == -INFINITY)) continue;       // nothing allowed yet for any query of this tile
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - m_use);
+            float ps = 0.f, pd[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = ok[r] ? __expf(st[r] - m_use) : 0.f;
+                ps += p;
+                const int key = kt * 32 + mrow(r, kh);
+                pd[r] = dp.apply(p, ((uint64_t)blockIdx.x * Lq + (uint64_t)q) * Lk + (uint64_t)key);
+            }
+            l_run = l_run * alpha + ps;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    const float va = Vs[(kt * 32 + mrow(s, kh)) * DVL + i * 32 + l31];
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(va, pd[s], acc[i], 0, 0, 0);
+                }
+            }
+        }
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float inv = 1.f / l_tot;                    // 0 allowed keys -> 0 * inf = NaN, like SDPA
+        if (kh == 0 && q < Lq) d.lse[((size_t)blockIdx.x) * Lq + q] = m_run + __logf(l_tot);
+        // ---- O^T (rows d, lane = query) -> scratch [q][d] -> coalesced rows, output dropout fused
+        wave_lds_fence();
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[l31 * SLD + i * 32 + mrow(r, kh)] = acc[i][r] * inv;
+        wave_lds_fence();
+        {
+            constexpr int C4 = DH / 4;
+            for (int idx = lane; idx < 32 * C4; idx += 64) {
+                const int row = idx / C4, c = idx % C4;
+                if (q0 + row < Lq) {
+                    const float* p = sc + row * SLD + 4 * c;
+                    const uint64_t base = ((uint64_t)b * Lq + (uint64_t)(q0 + row)) * (uint64_t)(d.heads * DH) + (uint64_t)(h * DH + 4 * c);
+                    float4 v;
+                    v.x = dout.apply(p[0], base + 0); v.y = dout.apply(p[1], base + 1);
+                    v.z = dout.apply(p[2], base + 2); v.w = dout.apply(p[3], base + 3);
+                    io<T>::st4(og + (size_t)(q0 + row) * d.ldo + 4 * c, v);
+                }
+            }
+        }
+    }
+}
+
+// ============================================================================ backward
+template <typename T, int DH>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const mmfm_attn_desc d) {
+    constexpr int DT = (DH + 31) / 32;
+    constexpr int LD = DH + 1;
+    constexpr int SLD = 33;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kh = lane >> 5, l31 = lane & 31;
+    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int Lq = d.Lq, Lk = d.Lk;
+    const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31;
+    const int Lmx = max(Lq, Lk);
+    float* Qs = smem;                       // [LqP][LD]
+    float* dOs = Qs + LqP * LD;             // [LqP][LD]   dO = dropout'(d_o)
+    float* Ks = dOs + LqP * LD;             // [LkP][LD]
+    float* Vs = Ks + LkP * LD;              // [LkP][LD]
+    float* lse = Vs + LkP * LD;             // [LqP]
+    float* dlt = lse + LqP;                 // [LqP]  delta = rowsum(d_o * o)
+    float* Sc = dlt + LqP;                  // [4][32][SLD]
+    uint8_t* kpad = reinterpret_cast<uint8_t*>(Sc + 4 * 32 * SLD);
+    uint8_t* modl = kpad + LkP;
+
+    const T* qg = reinterpret_cast<const T*>(d.q) + (size_t)b * Lq * d.ldq + h * DH;
+    const T* kg = reinterpret_cast<const T*>(d.k) + (size_t)b * Lk * d.ldk + h * DH;
+    const T* vg = reinterpret_cast<const T*>(d.v) + (size_t)b * Lk * d.ldv + h * DH;
+    const T* og = reinterpret_cast<const T*>(d.o) + (size_t)b * Lq * d.ldo + h * DH;
+    const T* dog = reinterpret_cast<const T*>(d.d_o) + (size_t)b * Lq * d.lddo + h * DH;
+    const Drop dp = drop_init(d.drop_p), dout = drop_init(d.drop_o);
+
+    load_head<T, DH>(Qs, LD, qg, d.ldq, Lq, LqP, t, 256);
+    load_head<T, DH>(Ks, LD, kg, d.ldk, Lk, LkP, t, 256);
+    load_head<T, DH>(Vs, LD, vg, d.ldv, Lk, LkP, t, 256);
+    {   // dO (output-dropout backward applied) and delta = sum_d d_o * o  (o = forward output AFTER drop_o)
+        constexpr int C4 = DH / 4;
+        for (int idx = t; idx < LqP * C4; idx += 256) {
+            const int row = idx / C4, c = idx % C4;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f), o = g;
+            if (row < Lq) {
+                g = io<T>::ld4(dog + (size_t)row * d.lddo + 4 * c);
+                o = io<T>::ld4(og + (size_t)row * d.ldo + 4 * c);
+            }
+            float part = g.x * o.x + g.y * o.y + g.z * o.z + g.w * o.w;
+#pragma unroll
+            for (int off = 1; off < C4; off <<= 1) part += __shfl_xor(part, off);
+            if (c == 0) dlt[row] = part;
+            const uint64_t base = ((uint64_t)b * Lq + (uint64_t)row) * (uint64_t)(d.heads * DH) + (uint64_t)(h * DH + 4 * c);
+            float* p = dOs + row * LD + 4 * c;
+            p[0] = dout.apply(g.x, base + 0); p[1] = dout.apply(g.y, base + 1);
+            p[2] = dout.apply(g.z, base + 2); p[3] = dout.apply(g.w, base + 3);
+        }
+    }
+    for (int i = t; i < LqP; i += 256) lse[i] = (i < Lq) ? d.lse[(size_t)blockIdx.x * Lq + i] : 0.f;
+    for (int i = t; i < LkP; i += 256) kpad[i] = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
+    if (d.flags & MMFM_ATTN_SEP)
+        for (int i = t; i < Lmx; i += 256) modl[i] = d.mod_id[i];
+    __syncthreads();
+
+    MaskCtx mk{kpad, modl, modl, d.flags};
+    float* sc = Sc + wave * 32 * SLD;
+    const int nqt = LqP / 32, nkt = LkP / 32;
+    const uint64_t pbase = (uint64_t)blockIdx.x * Lq;
+
+    // ---------------- phase A: wave owns key tile kt -> dK, dV
+    for (int kt = wave; kt < nkt; kt += 4) {
+        f32x16 dKt[DT], dVt[DT];
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dKt[i][r] = 0.f; dVt[i][r] = 0.f; }
+        const int key = kt * 32 + l31;
+        const float* kb = Ks + (kt * 32 + l31) * LD + kh;
+        const float* vb = Vs + (kt * 32 + l31) * LD + kh;
+        for (int qt = 0; qt < nqt; ++qt) {
+            f32x16 s, dpv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dpv[r] = 0.f; }
+            const float* qa = Qs + (qt * 32 + l31) * LD + kh;
+            const float* da = dOs + (qt * 32 + l31) * LD + kh;
+#pragma unroll
+            for (int k2 = 0; k2 < DH / 2; ++k2) {
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[2 * k2], kb[2 * k2], s, 0, 0, 0);       // S[q][key]
+                dpv = __builtin_amdgcn_mfma_f32_32x32x2f32(da[2 * k2], vb[2 * k2], dpv, 0, 0, 0);   // dP[q][key]
+            }
+            float pd[16], ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qt * 32 + mrow(r, kh);
+                const bool ok = (q < Lq) && (key < Lk) && mk.allowed(q, key);
+                const float p = ok ? __expf(s[r] * d.scale - lse[q]) : 0.f;
+                const uint64_t idx = (pbase + (uint64_t)q) * Lk + (uint64_t)key;
+                const bool keep = !dp.on() || dp.keep(idx);
+                pd[r] = keep ? p * dp.scale : 0.f;
+                const float dpd = keep ? dpv[r] * dp.scale : 0.f;
+                ds[r] = p * (dpd - dlt[q]) * d.scale;
+            }
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const int dcol = i * 32 + l31;
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) {
+                    const int qrow = qt * 32 + mrow(k2, kh);
+                    const float doT = (dcol < DH) ? dOs[qrow * LD + dcol] : 0.f;
+                    const float qT = (dcol < DH) ? Qs[qrow * LD + dcol] : 0.f;
+                    dVt[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(doT, pd[k2], dVt[i], 0, 0, 0);   // dV^T[d][key]
+                    dKt[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(qT, ds[k2], dKt[i], 0, 0, 0);    // dK^T[d][key]
+                }
+            }
+        }
+        // transpose through the wave's scratch, store coalesced rows
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            T* outg = reinterpret_cast<T*>(which ? d.dv : d.dk) + (size_t)b * Lk * (which ? d.lddv : d.lddk) + h * DH;
+            const int ldo_ = which ? d.lddv : d.lddk;
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                wave_lds_fence();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[l31 * SLD + mrow(r, kh)] = which ? dVt[i][r] : dKt[i][r];
+                wave_lds_fence();
+                constexpr int CW = (DH < 32 ? DH : 32) / 4;
+                for (int idx = lane; idx < 32 * CW; idx += 64) {
+                    const int row = idx / CW, c = idx % CW;
+                    if (kt * 32 + row < Lk) {
+                        const float* p = sc + row * SLD + 4 * c;
+                        io<T>::st4(outg + (size_t)(kt * 32 + row) * ldo_ + i * 32 + 4 * c, make_float4(p[0], p[1], p[2], p[3]));
+                    }
+                }
+            }
+        }
+    }
+
+    // ---------------- phase B: wave owns query tile qt -> dQ
+    for (int qt = wave; qt < nqt; qt += 4) {
+        f32x16 dQt[DT];
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dQt[i][r] = 0.f;
+        const int q = qt * 32 + l31;
+        const float lq = lse[q], dq_ = dlt[q];
+        const float* qb = Qs + (qt * 32 + l31) * LD + kh;
+        const float* db = dOs + (qt * 32 + l31) * LD + kh;
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x16 s, dpv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dpv[r] = 0.f; }
+            const float* ka = Ks + (kt * 32 + l31) * LD + kh;
+            const float* va = Vs + (kt * 32 + l31) * LD + kh;
+#pragma unroll
+            for (int k2 = 0; k2 < DH / 2; ++k2) {
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[2 * k2], qb[2 * k2], s, 0, 0, 0);       // S^T[key][q]
+                dpv = __builtin_amdgcn_mfma_f32_32x32x2f32(va[2 * k2], db[2 * k2], dpv, 0, 0, 0);   // dP^T[key][q]
+            }
+            float ds[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + mrow(r, kh);
+                const bool ok = (q < Lq) && (key < Lk) && mk.allowed(q, key);
+                const float p = ok ? __expf(s[r] * d.scale - lq) : 0.f;
+                const uint64_t idx = (pbase + (uint64_t)q) * Lk + (uint64_t)key;
+                const bool keep = !dp.on() || dp.keep(idx);
+                const float dpd = keep ? dpv[r] * dp.scale : 0.f;
+                ds[r] = p * (dpd - dq_) * d.scale;
+            }
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const int dcol = i * 32 + l31;
+#pragma unroll
+                for (int k2 = 0; k2 < 16; ++k2) {
+                    const float kT = (dcol < DH) ? Ks[(kt * 32 + mrow(k2, kh)) * LD + dcol] : 0.f;
+                    dQt[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(kT, ds[k2], dQt[i], 0, 0, 0);    // dQ^T[d][q]
+                }
+            }
+        }
+        T* outg = reinterpret_cast<T*>(d.dq) + (size_t)b * Lq * d.lddq + h * DH;
+#pragma unroll
+        for (int i = 0; i < DT; ++i) {
+            wave_lds_fence();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[l31 * SLD + mrow(r, kh)] = dQt[i][r];
+            wave_lds_fence();
+            constexpr int CW = (DH < 32 ? DH : 32) / 4;
+            for (int idx = lane; idx < 32 * CW; idx += 64) {
+                const int row = idx / CW, c = idx % CW;
+                if (qt * 32 + row < Lq) {
+                    const float* p = sc + row * SLD + 4 * c;
+                    io<T>::st4(outg + (size_t)(qt * 32 + row) * d.lddq + i * 32 + 4 * c, make_float4(p[0], p[1], p[2], p[3]));
+                }
+            }
+        }
+    }
+}
+
+size_t fwd_lds_bytes(int Lq, int Lk, int dh) {
+    const int DT = (dh + 31) / 32, LkP = (Lk + 31) & ~31, DVL = DT * 32;
+    return (size_t)(LkP * (dh + 1) + LkP * DVL + 4 * 32 * (DVL + 1)) * 4 + LkP + std::max(Lq, Lk) + 16;
+}
+size_t bwd_lds_bytes(int Lq, int Lk, int dh) {
+    const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31;
+    return (size_t)(2 * LqP * (dh + 1) + 2 * LkP * (dh + 1) + 2 * LqP + 4 * 32 * 33) * 4 + LkP + std::max(Lq, Lk) + 16;
+}
+
+// Opt in to > 64 KiB of dynamic LDS once per kernel (not a stream operation; done on the first,
+// un-captured call so later graph captures see no attribute change).
+template <typename K>
+int set_lds(K kern, size_t bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, size_t> done;
+    if (bytes <= 65536) return 0;
+    const void* key = reinterpret_cast<const void*>(kern);
+    std::lock_guard<std::mutex> g(mu);
+    auto it = done.find(key);
+    if (it != done.end() && it->second >= bytes) return 0;
+    hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return mmfm_set_error((int)e, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
+    done[key] = 160 * 1024;
+    return 0;
+}
+
+int check_common(const mmfm_attn_desc& d, const char* who) {
+    MMFM_REQUIRE(d.dtype == MMFM_F32 || d.dtype == MMFM_BF16, "%s: bad dtype", who);
+    MMFM_REQUIRE(d.B > 0 && d.heads > 0 && d.Lq > 0 && d.Lk > 0, "%s: bad shape", who);
+    MMFM_REQUIRE(d.dh == 8 || d.dh == 16 || d.dh == 32 || d.dh == 64, "%s: head dim %d not in {8,16,32,64}", who, d.dh);
+    MMFM_REQUIRE(d.q && d.k && d.v && d.o && d.lse, "%s: null tensor", who);
+    const int hd = d.heads * d.dh, al = 4;
+    MMFM_REQUIRE(d.ldq >= hd && d.ldk >= hd && d.ldv >= hd && d.ldo >= hd, "%s: leading dim < heads*dh", who);
+    MMFM_REQUIRE(d.ldq % al == 0 && d.ldk % al == 0 && d.ldv % al == 0 && d.ldo % al == 0, "%s: leading dims must be multiples of 4", who);
+    const size_t esz = d.dtype == MMFM_F32 ? 16 : 8;
+    MMFM_REQUIRE((uintptr_t)d.q % esz == 0 && (uintptr_t)d.k % esz == 0 && (uintptr_t)d.v % esz == 0 && (uintptr_t)d.o % esz == 0,
+                 "%s: q/k/v/o must be %zu-byte aligned", who, esz);
+    MMFM_REQUIRE((d.flags & MMFM_ATTN_CAUSAL) || d.keypad, "%s: keypad required unless CAUSAL", who);
+    MMFM_REQUIRE(!(d.flags & MMFM_ATTN_SEP) || d.mod_id, "%s: SEP needs mod_id", who);
+    MMFM_REQUIRE(!(d.flags & (MMFM_ATTN_DIAG | MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP)) || d.Lq == d.Lk, "%s: DIAG/CAUSAL/SEP need Lq == Lk", who);
+    return 0;
+}
+
+}  // namespace
+
+#define ATTN_DISPATCH(KERN, TT, DHV)                                                             \
+    {                                                                                            \
+        auto kern = KERN<TT, DHV>;                                                               \
+        if (int rc = set_lds(kern, lds)) return rc;                                              \
+        hipLaunchKernelGGL(kern, dim3(d.B * d.heads), dim3(256), lds, (hipStream_t)stream, d);   \
+    }
+
+#define ATTN_DISPATCH_ALL(KERN)                                                  \
+    if (d.dtype == MMFM_F32) {                                                   \
+        switch (d.dh) {                                                          \
+            case 8: ATTN_DISPATCH(KERN, float, 8) break;                         \
+            case 16: ATTN_DISPATCH(KERN, float, 16) break;                       \
+            case 32: ATTN_DISPATCH(KERN, float, 32) break;                       \
+            default: ATTN_DISPATCH(KERN, float, 64) break;                       \
+        }                                                                        \
+    } else {                                                                     \
+        switch (d.dh) {                                                          \
+            case 8: ATTN_DISPATCH(KERN, uint16_t, 8) break;                      \
+            case 16: ATTN_DISPATCH(KERN, uint16_t, 16) break;                    \
+            case 32: ATTN_DISPATCH(KERN, uint16_t, 32) break;                    \
+            default: ATTN_DISPATCH(KERN, uint16_t, 64) break;                    \
+        }                                                                        \
+    }
+
+extern "C" int mmfm_attn_fwd(const mmfm_attn_desc* dp, mmfm_stream stream) {
+    MMFM_REQUIRE(dp, "mmfm_attn_fwd: null descriptor");
+    const mmfm_attn_desc d = *dp;
+    if (int rc = check_common(d, "mmfm_attn_fwd")) return rc;
+    const size_t lds = fwd_lds_bytes(d.Lq, d.Lk, d.dh);
+    MMFM_REQUIRE(lds <= 160 * 1024, "mmfm_attn_fwd: Lk=%d dh=%d needs %zu B of LDS (> 160 KiB): key tiling not built yet", d.Lk, d.dh, lds);
+    ATTN_DISPATCH_ALL(attn_fwd_kernel)
+    MMFM_LAUNCH_CHECK("mmfm_attn_fwd");
+    return 0;
+}
+
+extern "C" int mmfm_attn_bwd(const mmfm_attn_desc* dp, mmfm_stream stream) {
+    MMFM_REQUIRE(dp, "mmfm_attn_bwd: null descriptor");
+    const mmfm_attn_desc d = *dp;
+    if (int rc = check_common(d, "mmfm_attn_bwd")) return rc;
+    MMFM_REQUIRE(d.d_o && d.dq && d.dk && d.dv, "mmfm_attn_bwd: null gradient tensor");
+    const int hd = d.heads * d.dh;
+    MMFM_REQUIRE(d.lddo >= hd && d.lddq >= hd && d.lddk >= hd && d.lddv >= hd, "mmfm_attn_bwd: gradient leading dim < heads*dh");
+    MMFM_REQUIRE(d.lddo % 4 == 0 && d.lddq % 4 == 0 && d.lddk % 4 == 0 && d.lddv % 4 == 0, "mmfm_attn_bwd: gradient leading dims must be multiples of 4");
+    const size_t lds = bwd_lds_bytes(d.Lq, d.Lk, d.dh);
+    MMFM_REQUIRE(lds <= 160 * 1024, "mmfm_attn_bwd: Lq=%d Lk=%d dh=%d needs %zu B of LDS (> 160 KiB): tiling not built yet", d.Lq, d.Lk, d.dh, lds);
+    ATTN_DISPATCH_ALL(attn_bwd_kernel)
+    MMFM_LAUNCH_CHECK("mmfm_attn_bwd");
+    return 0;
+}

@@ -1,0 +1,287 @@
+// GEMM for every nn.Linear forward/backward on the path (see include/mmfm.h, mmfm_gemm).
+//
+// fp32 (parity) path: v_mfma_f32_32x32x2_f32 — bit-for-bit a k-ordered fmaf chain per output
+// element, at the fp32 vector rate (157 TF dense on MI355X).  128x128x32 tile, 4 wavefronts
+// (2x2), each wave a 64x64 sub-tile = 2x2 MFMA tiles (64 accumulator VGPRs).
+//
+// Operand tiles live in LDS K-MAJOR ([k][row], row contiguous) whatever the global layout,
+// so the MFMA operand read `tile[k = 2s + lane/32][row0 + lane%32]` is 32 consecutive dwords
+// per half-wave: conflict-free.  The loader picks its thread->element map from the operand's
+// contiguous axis so global reads stay 16 B/lane and coalesced:
+//   K-contiguous (x[M,K], W[N,K]):    8 lanes x float4 = one 128-B row segment, transposed on the
+//                                     LDS write (ds_write_b32 x4);
+//   row-contiguous (dY^T, W for dX):  32 lanes x float4 = 512 B of one k-row, ds_write_b128.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDT = 132;  // LDS row stride (floats): 528 B keeps ds_write_b128 rows 16-B aligned
+constexpr int NTHREADS = 256;
+
+// ---- global -> registers (one 128 x 32 operand tile = 4 float4 per thread)
+template <bool KC>
+__device__ __forceinline__ void g2r(float4 (&r)[4], const float* __restrict__ base, int ld, int row0, int k0,
+                                    int rows, int kend, bool vec, int t) {
+    if (KC) {
+        const int kq = t & 7, r0 = t >> 3;
+        const int k = k0 + 4 * kq;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = row0 + r0 + 32 * p;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < rows && k < kend) {
+                const float* src = base + (size_t)row * ld + k;
+                if (vec && k + 3 < kend) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (k + 1 < kend) v.y = src[1];
+                    if (k + 2 < kend) v.z = src[2];
+                    if (k + 3 < kend) v.w = src[3];
+                }
+            }
+            r[p] = v;
+        }
+    } else {
+        const int rq = t & 31, kk0 = t >> 5;
+        const int row = row0 + 4 * rq;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int k = k0 + kk0 + 8 * p;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < kend && row < rows) {
+                const float* src = base + (size_t)k * ld + row;
+                if (vec && row + 3 < rows) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    v.x = src[0];
+                    if (row + 1 < rows) v.y = src[1];
+                    if (row + 2 < rows) v.z = src[2];
+                    if (row + 3 < rows) v.w = src[3];
+                }
+            }
+            r[p] = v;
+        }
+    }
+}
+
+// ---- registers -> LDS tile [BK][LDT]
+template <bool KC>
+__device__ __forceinline__ void r2s(float* __restrict__ S, const float4 (&r)[4], int t) {
+    if (KC) {
+        const int kq = t & 7, r0 = t >> 3;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = r0 + 32 * p;
+            S[(4 * kq + 0) * LDT + row] = r[p].x;
+            S[(4 * kq + 1) * LDT + row] = r[p].y;
+            S[(4 * kq + 2) * LDT + row] = r[p].z;
+            S[(4 * kq + 3) * LDT + row] = r[p].w;
+        }
+    } else {
+        const int rq = t & 31, kk0 = t >> 5;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            *reinterpret_cast<float4*>(&S[(kk0 + 8 * p) * LDT + 4 * rq]) = r[p];
+    }
+}
+
+// ---- fused epilogue for one element
+template <typename TO>
+__device__ __forceinline__ void epilogue_store(const mmfm_gemm_desc& d, const Drop& dr, float v, int m, int n) {
+    typedef io<TO> O;
+    if (d.bias) v += d.bias[n];
+    if (d.pre_out) O::st(reinterpret_cast<TO*>(d.pre_out) + (size_t)m * d.ldc + n, v);
+    if (d.act == 1) v = gelu_erf(v);
+    else if (d.act == 2) v = softsign_f(v) * d.act_scale;
+    if (d.gradmul_pre) {
+        const float u = O::ld(reinterpret_cast<const TO*>(d.gradmul_pre) + (size_t)m * d.ldc + n);
+        // act kinds 3/4 = multiply by gelu'(u) / softsign'(u)*scale (backward through the activation)
+        v *= (d.act == 3) ? gelu_erf_grad(u) : softsign_grad(u) * d.act_scale;
+    }
+    v = dr.apply(v, (uint64_t)m * (uint64_t)d.N + (uint64_t)n);
+    if (d.residual) v += O::ld(reinterpret_cast<const TO*>(d.residual) + (size_t)m * d.ldr + n);
+    O::st(reinterpret_cast<TO*>(d.C) + (size_t)m * d.ldc + n, v);
+}
+
+// XCD-aware block id: blocks b and b+8 share an XCD (round-robin dispatch), so give each XCD a
+// contiguous chunk of tile ids; tiles of one m-row then reuse the same A panel out of one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const mmfm_gemm_desc d, const int vecA, const int vecB) {
+    __shared__ __attribute__((aligned(16))) float As[BK * LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, kh = lane >> 5, l31 = lane & 31;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    const int z = blockIdx.y;
+    const int kbeg = z * d.kchunk;
+    const int kend = min(d.K, kbeg + d.kchunk);
+    const float* A = reinterpret_cast<const float*>(d.A);
+    const float* B = reinterpret_cast<const float*>(d.B);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[4], rb[4];
+    g2r<AKC>(ra, A, d.lda, m0, kbeg, d.M, kend, vecA, t);
+    g2r<BKC>(rb, B, d.ldb, n0, kbeg, d.N, kend, vecB, t);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();                       // previous tile's MFMA reads are done
+        r2s<AKC>(As, ra, t);
+        r2s<BKC>(Bs, rb, t);
+        __syncthreads();
+        if (k0 + BK < kend) {                  // prefetch the next tile under the MFMAs
+            g2r<AKC>(ra, A, d.lda, m0, k0 + BK, d.M, kend, vecA, t);
+            g2r<BKC>(rb, B, d.ldb, n0, k0 + BK, d.N, kend, vecB, t);
+        }
+        const float* a = As + wm * 64 + l31;
+        const float* b = Bs + wn * 64 + l31;
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            const int kk = 2 * ks + kh;
+            const float a0 = a[kk * LDT], a1 = a[kk * LDT + 32];
+            const float b0 = b[kk * LDT], b1 = b[kk * LDT + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+    // C/D map of the 32x32 MFMA: col = lane%32, row = (r&3) + 8*(r>>2) + 4*(lane/32)
+    if (d.splits > 1) {
+        float* C = reinterpret_cast<float*>(d.C) + (size_t)z * d.slab_stride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int n = n0 + wn * 64 + j * 32 + l31;
+                    if (m < d.M && n < d.N) C[(size_t)m * d.ldc + n] = acc[i][j][r];
+                }
+        return;
+    }
+    const Drop dr = drop_init(d.drop);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                if (m < d.M && n < d.N) epilogue_store<float>(d, dr, acc[i][j][r], m, n);
+            }
+}
+
+__global__ void reduce_slabs_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n, int nslabs,
+                                    int64_t stride, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float s = accumulate ? dst[i] : 0.f;
+        for (int k = 0; k < nslabs; ++k) s += src[(size_t)k * stride + i];
+        dst[i] = s;
+    }
+}
+
+// column sums: grid (ceil(N/64), S); block = 64 columns x 4 row lanes
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t R, int N, int ld, float* __restrict__ part,
+                                                     int64_t rows_per) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = min(R, r0 + rows_per);
+    float s = 0.f;
+    if (c < N)
+        for (int64_t r = r0 + rl; r < r1; r += 4) s += io<T>::ld(x + (size_t)r * ld + c);
+    red[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && c < N)
+        part[(size_t)blockIdx.y * N + c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+}  // namespace
+
+int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* d, hipStream_t st);  // gemm_bf16.hip
+
+extern "C" int mmfm_gemm(const mmfm_gemm_desc* dp, mmfm_stream stream) {
+    MMFM_REQUIRE(dp != nullptr, "mmfm_gemm: null descriptor");
+    mmfm_gemm_desc d = *dp;
+    MMFM_REQUIRE(d.dtype == MMFM_F32 || d.dtype == MMFM_BF16, "mmfm_gemm: bad dtype %d", d.dtype);
+    MMFM_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "mmfm_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
+    MMFM_REQUIRE(d.A && d.B && d.C, "mmfm_gemm: null operand");
+    MMFM_REQUIRE(d.lda >= (d.a_kcontig ? d.K : d.M), "mmfm_gemm: lda %d too small", d.lda);
+    MMFM_REQUIRE(d.ldb >= (d.b_kcontig ? d.K : d.N), "mmfm_gemm: ldb %d too small", d.ldb);
+    MMFM_REQUIRE(d.ldc >= d.N, "mmfm_gemm: ldc %d < N %d", d.ldc, d.N);
+    MMFM_REQUIRE(!(d.a_kcontig == 0 && d.b_kcontig == 1), "mmfm_gemm: layout (A row-contig, B k-contig) is not built");
+    MMFM_REQUIRE(d.act >= 0 && d.act <= 4, "mmfm_gemm: bad act %d", d.act);
+    MMFM_REQUIRE(!d.gradmul_pre || d.act == 3 || d.act == 4, "mmfm_gemm: gradmul_pre needs act 3 (gelu') or 4 (softsign')");
+    MMFM_REQUIRE(d.gradmul_pre || d.act <= 2, "mmfm_gemm: act %d needs gradmul_pre", d.act);
+    if (d.splits <= 1) {
+        d.splits = 1;
+        d.kchunk = d.K;
+    } else {
+        MMFM_REQUIRE(d.kchunk > 0 && d.kchunk % BK == 0, "mmfm_gemm: kchunk %d must be a positive multiple of %d", d.kchunk, BK);
+        MMFM_REQUIRE((int64_t)d.splits * d.kchunk >= d.K, "mmfm_gemm: splits*kchunk < K");
+        MMFM_REQUIRE(d.slab_stride >= (int64_t)d.M * d.ldc, "mmfm_gemm: slab_stride too small");
+        MMFM_REQUIRE(!d.bias && !d.pre_out && !d.act && !d.residual && d.drop.p <= 0.f,
+                     "mmfm_gemm: split-K writes raw partials, no epilogue");
+    }
+    MMFM_REQUIRE(!d.residual || d.ldr >= d.N, "mmfm_gemm: ldr too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (d.dtype == MMFM_BF16) return mmfm_gemm_bf16_launch(&d, st);
+
+    const int tiles = cdiv(d.M, BM) * cdiv(d.N, BN);
+    const int vecA = (d.lda % 4 == 0) && ((uintptr_t)d.A % 16 == 0);
+    const int vecB = (d.ldb % 4 == 0) && ((uintptr_t)d.B % 16 == 0);
+    dim3 grid(tiles, d.splits), block(NTHREADS);
+    if (d.a_kcontig && d.b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, true>), grid, block, 0, st, d, vecA, vecB);
+    else if (d.a_kcontig && !d.b_kcontig) hipLaunchKernelGGL((gemm_f32_kernel<true, false>), grid, block, 0, st, d, vecA, vecB);
+    else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, st, d, vecA, vecB);
+    MMFM_LAUNCH_CHECK("mmfm_gemm(f32)");
+    return 0;
+}
+
+extern "C" int mmfm_reduce_slabs(float* dst, const float* src, int64_t n, int nslabs, int64_t slab_stride,
+                                 int accumulate, mmfm_stream stream) {
+    MMFM_REQUIRE(dst && src && n > 0 && nslabs > 0 && slab_stride >= n, "mmfm_reduce_slabs: bad arguments");
+    const int blocks = (int)std::min<int64_t>(2048, (n + 255) / 256);
+    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, n, nslabs,
+                       slab_stride, accumulate);
+    MMFM_LAUNCH_CHECK("mmfm_reduce_slabs");
+    return 0;
+}
+
+static int colsum_splits(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(64, R / 256)); }
+
+extern "C" int64_t mmfm_colsum_workspace(int64_t R, int N) { return (int64_t)colsum_splits(R) * N * sizeof(float); }
+
+extern "C" int mmfm_colsum(int dtype, const void* x, int64_t R, int N, int ld, float* out, int accumulate,
+                           void* workspace, int64_t workspace_bytes, mmfm_stream stream) {
+    MMFM_REQUIRE(x && out && R > 0 && N > 0 && ld >= N, "mmfm_colsum: bad arguments");
+    const int S = colsum_splits(R);
+    MMFM_REQUIRE(workspace && workspace_bytes >= mmfm_colsum_workspace(R, N), "mmfm_colsum: workspace too small");
+    const int64_t rows_per = (R + S - 1) / S;
+    dim3 grid(cdiv(N, 64), S);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMFM_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, R, N, ld, (float*)workspace, rows_per);
+    else
+        hipLaunchKernelGGL(colsum_kernel<uint16_t>, grid, dim3(256), 0, st, (const uint16_t*)x, R, N, ld, (float*)workspace, rows_per);
+    MMFM_LAUNCH_CHECK("mmfm_colsum");
+    return mmfm_reduce_slabs(out, (const float*)workspace, N, S, N, accumulate, stream);
+}

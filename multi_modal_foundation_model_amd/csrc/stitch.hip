@@ -1,0 +1,186 @@
+// Mask/index preparation and the per-modality "stitch" (tokens + modality/position embeddings
+// scattered into the concatenated [B, M*T, H] sequence), forward and backward.
+// mm.py:90-110,141-175,245-275; encoder_embeddings.py:56-61; decoder_embeddings.py:56-61.
+// HBM-bound elementwise/gather work; index semantics are bit-exact (sample-0 quirk included).
+#include "common.h"
+#include <algorithm>
+
+namespace {
+
+constexpr int MAXM = 8;
+struct MaskSrc {
+    const int64_t* p[MAXM];
+    int64_t stride[MAXM];
+    int64_t channels[MAXM];
+};
+
+__global__ void mask_prep_kernel(MaskSrc src, const int64_t* __restrict__ attn, int B, int T, int M, uint8_t* __restrict__ tokmask,
+                                 uint8_t* __restrict__ keypad, uint8_t* __restrict__ keep0, uint8_t* __restrict__ mod_id,
+                                 unsigned long long* __restrict__ count) {
+    const int L = M * T;
+    unsigned long long local[MAXM];
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) local[m] = 0;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)B * L; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int b = (int)(idx / L), l = (int)(idx % L), m = l / T, t = l % T;
+        const int64_t a = attn[(size_t)b * T + t];
+        const int64_t v = src.p[m][((size_t)b * T + t) * src.stride[m]] & a;      // mm.py:270
+        tokmask[idx] = (uint8_t)(v != 0);
+        keypad[idx] = (uint8_t)(a != 0);
+        if (b == 0) {
+            keep0[l] = (uint8_t)(v != 1);                                            // mm.py:145: argwhere(mask[0] == 1)
+            mod_id[l] = (uint8_t)m;
+        }
+#pragma unroll
+        for (int mm = 0; mm < MAXM; ++mm)
+            if (mm == m) local[mm] += (unsigned long long)v * (unsigned long long)src.channels[mm];
+    }
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+        if (m < M) {
+            unsigned long long s = local[m];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if ((threadIdx.x & 63) == 0 && s) atomicAdd(&count[m], s);              // integer: order-independent, exact
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void stitch_fwd_kernel(const T* __restrict__ tok, const float* __restrict__ mod_row,
+                                                         const float* __restrict__ pos, const int64_t* __restrict__ ts,
+                                                         const uint8_t* __restrict__ keep0, T* __restrict__ x, T* __restrict__ emb,
+                                                         int B, int Tn, int L, int m, int H, int max_F) {
+    const int C4 = H / 4;
+    const int64_t total = (int64_t)B * Tn * C4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / C4;
+        const int c = (int)(idx % C4) * 4;
+        const int b = (int)(r / Tn), t = (int)(r % Tn);
+        const int l = m * Tn + t;
+        const float4 mr = *reinterpret_cast<const float4*>(mod_row + c);
+        const int tsv = (int)min((int64_t)(max_F - 1), max((int64_t)0, ts[r]));     // memory-safe even for bad stamps
+        const float4 pr = *reinterpret_cast<const float4*>(pos + (size_t)tsv * H + c);
+        float4 e = make_float4(mr.x + pr.x, mr.y + pr.y, mr.z + pr.z, mr.w + pr.w);
+        const size_t o = ((size_t)b * L + l) * H + c;
+        if (emb) io<T>::st4(emb + o, e);
+        if (keep0[l]) {
+            const float4 tv = io<T>::ld4(tok + (size_t)r * H + c);
+            e.x += tv.x; e.y += tv.y; e.z += tv.z; e.w += tv.w;
+        }
+        io<T>::st4(x + o, e);
+    }
+}
+
+// block = CW threads (one column each); grid = (H/CW, nchunks); LDS table [max_F][CW]
+template <typename T>
+__global__ void stitch_bwd_kernel(const T* __restrict__ dx, const T* __restrict__ dextra, const int64_t* __restrict__ ts,
+                                  const uint8_t* __restrict__ keep0, mmfm_dropout dropa, T* __restrict__ d_tok,
+                                  float* __restrict__ part, int B, int Tn, int L, int m, int H, int max_F, int bper) {
+    extern __shared__ __attribute__((aligned(16))) float tab[];
+    const int CW = blockDim.x, j = threadIdx.x, col = blockIdx.x * CW + j;
+    const Drop dr = drop_init(dropa);
+    for (int f = 0; f < max_F; ++f) tab[f * CW + j] = 0.f;
+    float macc = 0.f;
+    const int b0 = blockIdx.y * bper, b1 = min(B, b0 + bper);
+    for (int b = b0; b < b1; ++b) {
+        for (int t = 0; t < Tn; ++t) {
+            const int l = m * Tn + t;
+            const size_t o = ((size_t)b * L + l) * H + col;
+            const float g = io<T>::ld(dx + o);
+            float e = g;
+            if (dextra) e += io<T>::ld(dextra + o);
+            const int64_t r = (int64_t)b * Tn + t;
+            const int tsv = (int)min((int64_t)(max_F - 1), max((int64_t)0, ts[r]));
+            tab[tsv * CW + j] += e;                   // a thread owns its column: no race, fixed order
+            macc += e;
+            if (d_tok) io<T>::st(d_tok + (size_t)r * H + col, keep0[l] ? dr.apply(g, (uint64_t)r * H + col) : 0.f);
+        }
+    }
+    float* out = part + (size_t)blockIdx.y * (max_F + 1) * H;
+    for (int f = 0; f < max_F; ++f) out[(size_t)f * H + col] = tab[f * CW + j];
+    out[(size_t)max_F * H + col] = macc;
+}
+
+int pick_cw(int H, int max_F) {
+    for (int cw : {256, 128, 64, 32, 16, 8, 4})
+        if (H % cw == 0 && (size_t)max_F * cw * 4 <= 60 * 1024) return cw;
+    return 0;
+}
+int stitch_chunks(int B, int H, int cw) { return std::max(1, std::min(B, 512 / std::max(1, H / cw))); }
+
+}  // namespace
+
+extern "C" int mmfm_reduce_slabs(float*, const float*, int64_t, int, int64_t, int, mmfm_stream);
+
+extern "C" int mmfm_mask_prep(int B, int T, int M, const int64_t* const* mask_src, const int64_t* mask_stride,
+                              const int64_t* attn, const int64_t* channels, uint8_t* tokmask, uint8_t* keypad,
+                              uint8_t* keep0, uint8_t* mod_id, int64_t* count, mmfm_stream stream) {
+    MMFM_REQUIRE(B > 0 && T > 0 && M > 0 && M <= MAXM, "mmfm_mask_prep: bad shape B=%d T=%d M=%d (M <= %d)", B, T, M, MAXM);
+    MMFM_REQUIRE(mask_src && mask_stride && attn && channels && tokmask && keypad && keep0 && mod_id && count, "mmfm_mask_prep: null pointer");
+    MMFM_REQUIRE(M * T <= 65535, "mmfm_mask_prep: sequence too long");
+    MaskSrc src;
+    for (int m = 0; m < MAXM; ++m) {
+        src.p[m] = m < M ? mask_src[m] : nullptr;
+        src.stride[m] = m < M ? mask_stride[m] : 0;
+        src.channels[m] = m < M ? channels[m] : 0;
+        MMFM_REQUIRE(m >= M || (src.p[m] && src.stride[m] > 0), "mmfm_mask_prep: modality %d has no mask source", m);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(count, 0, sizeof(int64_t) * M, st);
+    if (e != hipSuccess) return mmfm_set_error((int)e, "mmfm_mask_prep: memset: %s", hipGetErrorString(e));
+    const int64_t n = (int64_t)B * M * T;
+    hipLaunchKernelGGL(mask_prep_kernel, dim3((int)std::min<int64_t>(256, (n + 255) / 256)), dim3(256), 0, st, src, attn, B, T, M,
+                       tokmask, keypad, keep0, mod_id, (unsigned long long*)count);
+    MMFM_LAUNCH_CHECK("mmfm_mask_prep");
+    return 0;
+}
+
+extern "C" int mmfm_stitch_fwd(int dtype, const void* tok, const float* mod_emb_row, const float* pos_emb, const int64_t* ts,
+                               const uint8_t* keep0, void* x, void* emb, int B, int T, int L, int m, int H, int max_F, mmfm_stream stream) {
+    MMFM_REQUIRE(tok && mod_emb_row && pos_emb && ts && keep0 && x, "mmfm_stitch_fwd: null pointer");
+    MMFM_REQUIRE(B > 0 && T > 0 && H > 0 && H % 4 == 0 && m >= 0 && (m + 1) * T <= L && max_F > 0, "mmfm_stitch_fwd: bad shape");
+    const int64_t n = (int64_t)B * T * (H / 4);
+    dim3 grid((int)std::min<int64_t>(4096, (n + 255) / 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMFM_F32)
+        hipLaunchKernelGGL(stitch_fwd_kernel<float>, grid, block, 0, st, (const float*)tok, mod_emb_row, pos_emb, ts, keep0, (float*)x, (float*)emb, B, T, L, m, H, max_F);
+    else if (dtype == MMFM_BF16)
+        hipLaunchKernelGGL(stitch_fwd_kernel<uint16_t>, grid, block, 0, st, (const uint16_t*)tok, mod_emb_row, pos_emb, ts, keep0, (uint16_t*)x, (uint16_t*)emb, B, T, L, m, H, max_F);
+    else
+        return mmfm_set_error(-1, "mmfm_stitch_fwd: bad dtype %d", dtype);
+    MMFM_LAUNCH_CHECK("mmfm_stitch_fwd");
+    return 0;
+}
+
+extern "C" int64_t mmfm_stitch_bwd_workspace(int B, int T, int H, int max_F) {
+    const int cw = pick_cw(H, max_F);
+    if (!cw) return -1;
+    return (int64_t)stitch_chunks(B, H, cw) * (max_F + 1) * H * sizeof(float);
+}
+
+extern "C" int mmfm_stitch_bwd(int dtype, const void* dx, const void* dextra, const int64_t* ts, const uint8_t* keep0,
+                               mmfm_dropout drop, void* d_tok, float* d_mod_row, float* d_pos, int accumulate, int B, int T,
+                               int L, int m, int H, int max_F, void* workspace, int64_t workspace_bytes, mmfm_stream stream) {
+    MMFM_REQUIRE(dx && ts && keep0 && d_mod_row && d_pos, "mmfm_stitch_bwd: null pointer");
+    MMFM_REQUIRE(B > 0 && T > 0 && H > 0 && max_F > 0 && m >= 0 && (m + 1) * T <= L, "mmfm_stitch_bwd: bad shape");
+    const int cw = pick_cw(H, max_F);
+    MMFM_REQUIRE(cw > 0, "mmfm_stitch_bwd: no column slab fits LDS for H=%d max_F=%d", H, max_F);
+    const int nch = stitch_chunks(B, H, cw);
+    MMFM_REQUIRE(workspace && workspace_bytes >= mmfm_stitch_bwd_workspace(B, T, H, max_F), "mmfm_stitch_bwd: workspace too small");
+    const int bper = (B + nch - 1) / nch;
+    dim3 grid(H / cw, nch), block(cw);
+    const size_t lds = (size_t)max_F * cw * sizeof(float);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == MMFM_F32)
+        hipLaunchKernelGGL(stitch_bwd_kernel<float>, grid, block, lds, st, (const float*)dx, (const float*)dextra, ts, keep0, drop, (float*)d_tok,
+                           (float*)workspace, B, T, L, m, H, max_F, bper);
+    else if (dtype == MMFM_BF16)
+        hipLaunchKernelGGL(stitch_bwd_kernel<uint16_t>, grid, block, lds, st, (const uint16_t*)dx, (const uint16_t*)dextra, ts, keep0, drop,
+                           (uint16_t*)d_tok, (float*)workspace, B, T, L, m, H, max_F, bper);
+    else
+        return mmfm_set_error(-1, "mmfm_stitch_bwd: bad dtype %d", dtype);
+    MMFM_LAUNCH_CHECK("mmfm_stitch_bwd");
+    const int64_t stride = (int64_t)(max_F + 1) * H;
+    if (int rc = mmfm_reduce_slabs(d_pos, (const float*)workspace, (int64_t)max_F * H, nch, stride, accumulate, stream)) return rc;
+    return mmfm_reduce_slabs(d_mod_row, (const float*)workspace + (size_t)max_F * H, H, nch, stride, accumulate, stream);
+}

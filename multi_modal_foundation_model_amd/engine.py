@@ -1,0 +1,588 @@
+"""The train-step engine: MultiModal forward / backward as a pre-bound plan of HIP kernel launches.
+
+Reference path: `MultiModal.forward` (src/multi_modal/mm.py:242-308) + autograd of it
+(`loss.backward()`, src/trainer/base.py:194-195).  Design (MI355X-first, not a translation):
+
+* all parameters live in ONE flat fp32 buffer (`P`), gradients in a second (`G`); the nn.Module
+  parameters of the API mirror are views into it.  The layout is forward order so that the
+  gradient ranges complete back-to-front during backward: the DDP wrapper all-reduces contiguous
+  buckets of `G` as soon as backward passes their start, overlapped with the rest of backward.
+  Q/K/V (and cross-attention K/V) weights are adjacent, so one GEMM does the fused projection.
+* activations/workspaces are allocated once per batch shape; a step is a fixed list of
+  (C function, bound arguments) pairs -> no per-step allocation, marshalling or host sync, and
+  the list can be captured into a hipGraph (`Engine.capture`).
+* backward is written by hand (no autograd graph): LayerNorm backward fuses the residual-gradient
+  add, dX GEMMs fuse the activation derivative, dW GEMMs are split-K over the token dimension with
+  a deterministic slab reduction, dropout masks are regenerated from a counter RNG.
+* there is no CPU / eager fallback: everything below calls libmmfm_hip.so.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops as K
+
+LOSS_KIND = {"ap": 0, "behavior": 1}       # mm.py:79-82: PoissonNLL(log_input) / MSE
+
+
+@dataclass
+class EngineConfig:
+    hidden: int
+    heads: int
+    inter: int
+    n_enc: int
+    n_dec: int
+    max_F: int
+    mult: int
+    n_modality: int
+    embed_scale: float
+    embed_dropout: float
+    dropout: float
+    sep_mask: bool
+    causal_mask: bool
+    mods: List[Tuple[str, int]]                 # (name, channels) in avail_mod order
+    loss_kind: Dict[str, int] = field(default_factory=lambda: dict(LOSS_KIND))
+
+    @staticmethod
+    def from_model_config(mc, mods) -> "EngineConfig":
+        et, ee = mc["encoder"]["transformer"], mc["encoder"]["embedder"]
+        dtf = mc["decoder"]["transformer"]
+        for k in ("hidden_size", "n_heads", "inter_size", "dropout"):
+            if et[k] != dtf[k]:
+                raise ValueError(f"encoder/decoder transformer.{k} differ ({et[k]} vs {dtf[k]}): not supported")
+        if et["use_scalenorm"] or dtf["use_scalenorm"]:
+            raise NotImplementedError("use_scalenorm=true has no HIP kernel (mm.yaml default is false)")
+        if et["act"] != "gelu" or ee["act"] != "softsign":
+            raise NotImplementedError("only act=gelu (transformer) / softsign (embedder) are built")
+        scale = et["hidden_size"] ** 0.5 if ee["scale"] is None else ee["scale"]
+        return EngineConfig(hidden=et["hidden_size"], heads=et["n_heads"], inter=et["inter_size"],
+                            n_enc=et["n_layers"], n_dec=dtf["n_layers"], max_F=ee["max_F"], mult=ee["mult"],
+                            n_modality=ee["n_modality"], embed_scale=float(scale), embed_dropout=ee["dropout"],
+                            dropout=et["dropout"], sep_mask=bool(mc["decoder"]["decoder_sep_mask"]),
+                            causal_mask=bool(mc["decoder"]["decoder_causal_mask"]), mods=list(mods))
+
+
+def _align(n, a=8):
+    return (n + a - 1) // a * a
+
+
+class ParamLayout:
+    """name -> (offset, shape) in the flat buffer; `groups` are the DDP buckets' atoms."""
+
+    def __init__(self, cfg: EngineConfig):
+        H, I = cfg.hidden, cfg.inter
+        self.entries: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.alias: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.segments: List[Tuple[str, int, int]] = []       # (segment name, start, end) in forward order
+        self.n = 0
+
+        def add(name, shape):
+            self.entries[name] = (self.n, tuple(shape))
+            self.n += int(math.prod(shape))
+
+        def pad():
+            self.n = _align(self.n)
+
+        def seg_begin():
+            pad()
+            return self.n
+
+        def lin(prefix, o, i):
+            pad(); add(prefix + ".weight", (o, i)); pad(); add(prefix + ".bias", (o,))
+
+        def ln(prefix):
+            pad(); add(prefix + ".weight", (H,)); pad(); add(prefix + ".bias", (H,))
+
+        def fused(prefix, names, alias):
+            pad()
+            start = self.n
+            for nm in names:
+                add(f"{prefix}.{nm}.weight", (H, H))
+            self.alias[f"{prefix}.{alias}.weight"] = (start, (len(names) * H, H))
+            pad()
+            start = self.n
+            for nm in names:
+                add(f"{prefix}.{nm}.bias", (H,))
+            self.alias[f"{prefix}.{alias}.bias"] = (start, (len(names) * H,))
+
+        s = seg_begin()
+        for side in ("encoder", "decoder"):
+            for mod, n in cfg.mods:
+                p = f"{side}_embeddings.{mod}.embedder"
+                lin(p + ".token_embed", n * cfg.mult, n)
+                lin(p + ".projection", H, n * cfg.mult)
+                if side == "encoder":       # decoder's mod_emb IS this tensor (mm.py:84-87)
+                    pad(); add(p + ".mod_emb.weight", (cfg.n_modality, H))
+                pad(); add(p + ".pos_embed.weight", (cfg.max_F, H))
+        pad()
+        self.segments.append(("embed", s, self.n))
+        for i in range(cfg.n_enc):
+            s = seg_begin()
+            p = f"encoder.{i}"
+            ln(p + ".ln1"); fused(p + ".attn", ("query", "key", "value"), "qkv"); lin(p + ".attn.out_proj", H, H)
+            ln(p + ".ln2"); lin(p + ".mlp.up_proj", I, H); lin(p + ".mlp.down_proj", H, I)
+            pad()
+            self.segments.append((p, s, self.n))
+        s = seg_begin()
+        ln("encoder_norm"); lin("decoder_proj_context", H, H)
+        pad()
+        self.segments.append(("bridge", s, self.n))
+        for i in range(cfg.n_dec):
+            s = seg_begin()
+            p = f"decoder.{i}"
+            ln(p + ".ln1"); fused(p + ".attn", ("query", "key", "value"), "qkv"); lin(p + ".attn.out_proj", H, H)
+            ln(p + ".query_norm"); ln(p + ".context_norm")
+            lin(p + ".cross_attn.query", H, H); fused(p + ".cross_attn", ("key", "value"), "kv")
+            lin(p + ".cross_attn.out_proj", H, H)
+            ln(p + ".ln2"); lin(p + ".mlp.up_proj", I, H); lin(p + ".mlp.down_proj", H, I)
+            pad()
+            self.segments.append((p, s, self.n))
+        s = seg_begin()
+        ln("decoder_norm")
+        for mod, n in cfg.mods:
+            lin(f"decoder_embeddings.{mod}.out", n, H)
+        pad()
+        self.segments.append(("head", s, self.n))
+        self.n = _align(self.n, 64)
+
+    def view(self, flat, name):
+        off, shape = self.entries[name] if name in self.entries else self.alias[name]
+        return flat[off: off + int(math.prod(shape))].view(shape)
+
+
+class _StepFn(torch.autograd.Function):
+    """Connects the engine to `loss.backward()` (trainer/base.py:194-195)."""
+
+    @staticmethod
+    def forward(ctx, anchor, engine, token):
+        ctx.engine, ctx.token = engine, token
+        return engine.b["loss"].clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.engine.backward(grad_out, ctx.token)
+        return None, None, None
+
+
+class Engine:
+    def __init__(self, cfg: EngineConfig, device, dtype: str = "fp32", seed: int = 0):
+        if cfg.hidden % cfg.heads:
+            raise ValueError("Hidden dim is not multiple of head size")
+        if dtype not in ("fp32", "bf16"):
+            raise ValueError(dtype)
+        self.cfg, self.device = cfg, torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("the MI355X engine needs a CUDA/HIP device; there is no CPU fallback "
+                               "(the CPU restatement lives in oracle/ and is test infrastructure only)")
+        L.check(L.lib().mmfm_device_check(self.device.index or 0), "mmfm_device_check")
+        self.dtype = dtype
+        self.adt = torch.float32 if dtype == "fp32" else torch.bfloat16
+        self.code = L.F32 if dtype == "fp32" else L.BF16
+        self.layout = ParamLayout(cfg)
+        n = self.layout.n
+        self.P = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.G = torch.zeros(n, dtype=torch.float32, device=self.device)
+        self.Pw = self.P if dtype == "fp32" else torch.zeros(n, dtype=torch.bfloat16, device=self.device)
+        self.rng = torch.zeros(2, dtype=torch.int32, device=self.device)
+        K.rng_seed(self.rng, seed)
+        self.params: Dict[str, torch.nn.Parameter] = {}
+        self.plans: Dict[Tuple, dict] = {}
+        self.b: Dict[str, torch.Tensor] = {}
+        self._shape = None
+        self._token = 0
+        self._fwd_token = -1
+        self._sites: Dict[str, int] = {}
+        self.grad_ready_hooks = []       # DDP: callables(segment_name, start, end) fired during backward
+        self.b["loss"] = torch.zeros(1, device=self.device)
+        self.b["inv_n"] = torch.zeros(1, device=self.device)
+        self.b["gout"] = torch.ones(1, device=self.device)
+
+    # ------------------------------------------------------------------ parameters
+    def adopt(self, named_params: Dict[str, torch.nn.Parameter]):
+        """Copy the module's parameters into the flat buffer and re-point them at views of it."""
+        missing = set(self.layout.entries) - set(named_params)
+        extra = set(named_params) - set(self.layout.entries)
+        if missing or extra:
+            raise KeyError(f"parameter set mismatch: missing {sorted(missing)[:4]}, unexpected {sorted(extra)[:4]}")
+        with torch.no_grad():
+            for name, p in named_params.items():
+                v = self.layout.view(self.P, name)
+                if tuple(p.shape) != tuple(v.shape):
+                    raise ValueError(f"{name}: shape {tuple(p.shape)} != {tuple(v.shape)}")
+                v.copy_(p.data.to(self.device, torch.float32))
+                p.data = v
+                p.grad = None
+                self.params[name] = p
+        self.refresh_weights()
+
+    def owns(self, named_params) -> bool:
+        """True while the module's parameters are still views of our flat buffer (e.g. `.to()` breaks it)."""
+        lo, hi = self.P.data_ptr(), self.P.data_ptr() + self.P.numel() * 4
+        return all(lo <= p.data_ptr() < hi for p in named_params.values())
+
+    def refresh_weights(self):
+        """bf16 mode: refresh the bf16 weight copy from the fp32 master (the fused AdamW does it itself)."""
+        if self.dtype == "bf16":
+            K.cast_bf16(self.P, self.Pw, self.P.numel())
+
+    def W(self, name):
+        return self.layout.view(self.Pw, name)
+
+    def Pf(self, name):          # fp32 master view (LayerNorm affine, biases, embedding tables)
+        return self.layout.view(self.P, name)
+
+    def Gv(self, name):
+        return self.layout.view(self.G, name)
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, name, shape, dtype=None, zero=False):
+        dtype = self.adt if dtype is None else dtype
+        t = self.b.get(name)
+        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
+            self.b[name] = t
+        return t
+
+    def _site(self, key):
+        if key not in self._sites:
+            self._sites[key] = len(self._sites) + 1
+        return self._sites[key]
+
+    def _drop(self, key, p):
+        return K.dropout(self.rng, self._site(key), p) if p > 0 else None
+
+    # ------------------------------------------------------------------ plan construction
+    def _dw_split(self, M, N, R):
+        tiles = -(-M // 128) * -(-N // 128)
+        S = max(1, min(R // 256, max(1, 1024 // tiles)))
+        kchunk = _align(-(-R // S), 32)
+        return -(-R // kchunk), kchunk
+
+    def _plan(self, B, T, training):
+        key = (B, T, bool(training))
+        if key in self.plans:
+            return self.plans[key]
+        c = self.cfg
+        H, I, heads = c.hidden, c.inter, c.heads
+        dh = H // heads
+        M = len(c.mods)
+        Lq = M * T
+        R, BT = B * Lq, B * T
+        dp = c.dropout if training else 0.0
+        dpe = c.embed_dropout if training else 0.0
+        f32, i64, u8 = torch.float32, torch.int64, torch.uint8
+        buf = self._buf
+        fwd, bwd_tail = [], []
+        code = self.code
+
+        # ---- static inputs
+        for m, (mod, n) in enumerate(c.mods):
+            buf(f"in/{m}", (BT, n)); buf(f"tgt/{m}", (BT, n), f32); buf(f"mask/{m}", (B, T), i64)
+        ts, attn = buf("ts", (B, T), i64), buf("attn", (B, T), i64)
+        tokmask, keypad = buf("tokmask", (B, Lq), u8), buf("keypad", (B, Lq), u8)
+        keep0, mod_id, count = buf("keep0", (Lq,), u8), buf("mod_id", (Lq,), u8), buf("count", (M,), i64)
+        loss_sum = buf("loss_sum", (M,), f32)
+
+        # ---- workspaces
+        max_slab = 1
+        for _, n in c.mods:
+            for (mm, nn) in ((n * c.mult, n), (H, n * c.mult), (n, H)):
+                S, _ = self._dw_split(mm, nn, BT)
+                max_slab = max(max_slab, S * mm * nn)
+        for (mm, nn) in ((3 * H, H), (H, H), (2 * H, H), (I, H), (H, I)):
+            S, _ = self._dw_split(mm, nn, R)
+            max_slab = max(max_slab, S * mm * nn)
+        slab = buf("ws/slab", (max_slab,), f32)
+        maxN = max([3 * H, I] + [n * c.mult for _, n in c.mods])
+        ws_col = buf("ws/col", (max(1, L.lib().mmfm_colsum_workspace(R, maxN) // 4),), f32)
+        ws_ln = buf("ws/ln", (max(1, L.lib().mmfm_layernorm_bwd_workspace(R, H) // 4),), f32)
+        ws_st = buf("ws/stitch", (max(1, L.lib().mmfm_stitch_bwd_workspace(B, T, H, c.max_F) // 4),), f32)
+        ws_loss = buf("ws/loss", (max(1, L.lib().mmfm_masked_loss_workspace(BT, 1) // 4),), f32)
+
+        def lin(plan, X, wname, Y, Mr, N, Kd, **kw):
+            K.gemm(X, self.W(wname + ".weight"), Y, Mr, N, Kd, lda=Kd, ldb=Kd, ldc=N, bias=self.Pf(wname + ".bias"),
+                   dtype=code, plan=plan, **kw)
+
+        def dlin(plan, dY, X, wname, Mr, N, Kd, dX=None, **kw):
+            """Backward of Y[Mr,N] = X[Mr,Kd] @ W[N,Kd]^T + b:  dW, db into G;  dX = dY @ W (optional, fused epilogue)."""
+            S, kchunk = self._dw_split(N, Kd, Mr)
+            gw = self.Gv(wname + ".weight")
+            if S == 1:
+                K.gemm(dY, X, gw, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, dtype=code, c_f32=1, plan=plan)
+            else:
+                K.gemm(dY, X, slab, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
+                       slab_stride=N * Kd, dtype=code, c_f32=1, plan=plan)
+                K.reduce_slabs(gw, slab, N * Kd, S, N * Kd, plan=plan)
+            K.colsum(dY, Mr, N, N, self.Gv(wname + ".bias"), ws_col, plan=plan)
+            if dX is not None:
+                K.gemm(dY, self.W(wname + ".weight"), dX, Mr, Kd, N, lda=N, ldb=Kd, ldc=Kd, b_kcontig=0, dtype=code, plan=plan, **kw)
+
+        def ln_f(plan, X, name, Y, tag, **kw):
+            K.layernorm_fwd(X, self.Pf(name + ".weight"), self.Pf(name + ".bias"), Y, buf(tag + "/mean", (R,), f32),
+                            buf(tag + "/rstd", (R,), f32), R, H, plan=plan, **kw)
+
+        def ln_b(plan, dY, X, name, tag, dres, dX, **kw):
+            K.layernorm_bwd(dY, X, self.b[tag + "/mean"], self.b[tag + "/rstd"], self.Pf(name + ".weight"), dres, dX,
+                            self.Gv(name + ".weight"), self.Gv(name + ".bias"), R, H, ws_ln, plan=plan, **kw)
+
+        es = 4 if self.dtype == "fp32" else 2
+        scale = 1.0 / math.sqrt(dh)
+
+        def attn_desc(tag, q, ldq, kv, ldkv, koff, voff, o, flags, d_o=None, dq=None, dkv=None, lddq=0, lddkv=0, dkoff=0, dvoff=0):
+            return K.attn_desc(code, B, heads, Lq, Lq, dh, q.data_ptr(), kv.data_ptr() + koff * es, kv.data_ptr() + voff * es, ldq, ldkv, ldkv,
+                               o.data_ptr(), H, buf(tag + "/lse", (B, heads, Lq), f32), keypad, mod_id, flags, scale,
+                               drop_p=self._drop(tag + "/p", dp), drop_o=self._drop(tag + "/o", dp),
+                               d_o=None if d_o is None else d_o.data_ptr(), lddo=H,
+                               dq=None if dq is None else dq.data_ptr(),
+                               dk=None if dkv is None else dkv.data_ptr() + dkoff * es,
+                               dv=None if dkv is None else dkv.data_ptr() + dvoff * es, lddq=lddq, lddk=lddkv, lddv=lddkv)
+
+        enc_flags = L.ATTN_DIAG                                                # mm.py:152-158
+        dec_flags = (L.ATTN_CAUSAL if c.causal_mask else 0) | (L.ATTN_SEP if c.sep_mask else 0)   # mm.py:178-194
+
+        # ============================================================ forward
+        K.mask_prep(B, T, [self.b[f"mask/{m}"] for m in range(M)], [1] * M, attn, [n for _, n in c.mods], tokmask, keypad, keep0,
+                    mod_id, count, plan=fwd)
+        tok_tmp = buf("tok_tmp", (BT, H))
+        x_enc, emb_enc, x_dec = buf("x_enc", (R, H)), buf("emb_enc", (R, H)), buf("x_dec", (R, H))
+        for side, xs, es_ in (("encoder", x_enc, emb_enc), ("decoder", x_dec, None)):
+            for m, (mod, n) in enumerate(c.mods):
+                p = f"{side}_embeddings.{mod}.embedder"
+                n2 = n * c.mult
+                z, a = buf(f"{side}/z/{m}", (BT, n2)), buf(f"{side}/a/{m}", (BT, n2))
+                lin(fwd, self.b[f"in/{m}"], p + ".token_embed", a, BT, n2, n, pre_out=z, act=L.ACT_SOFTSIGN, act_scale=c.embed_scale)
+                lin(fwd, a, p + ".projection", tok_tmp, BT, H, n2, drop=self._drop(f"{side}/embdrop/{m}", dpe))
+                mod_row = self.Pf(f"encoder_embeddings.{mod}.embedder.mod_emb.weight")[m]
+                K.stitch_fwd(tok_tmp, mod_row, self.Pf(p + ".pos_embed.weight"), ts, keep0, xs, es_, B, T, Lq, m, H, c.max_F, plan=fwd)
+
+        def self_block(plan, X, p, tag, flags):
+            """x + attn(ln1(x))  (encoder_embeddings.py:112, decoder_embeddings.py:141)."""
+            h, qkv, a, Xa = buf(tag + "/h1", (R, H)), buf(tag + "/qkv", (R, 3 * H)), buf(tag + "/a", (R, H)), buf(tag + "/xa", (R, H))
+            ln_f(plan, X, p + ".ln1", h, tag + "/ln1")
+            lin(plan, h, p + ".attn.qkv", qkv, R, 3 * H, H)
+            K.attn_fwd(attn_desc(tag + "/sa", qkv, 3 * H, qkv, 3 * H, H, 2 * H, a, flags), plan=plan)
+            lin(plan, a, p + ".attn.out_proj", Xa, R, H, H, residual=X, ldr=H)
+            return Xa
+
+        def mlp_block(plan, X, p, tag):
+            """x + mlp(ln2(x))  (encoder_embeddings.py:114; mm_utils.py:50-52)."""
+            h, u, g, Xb = buf(tag + "/h2", (R, H)), buf(tag + "/u", (R, I)), buf(tag + "/g", (R, I)), buf(tag + "/xb", (R, H))
+            ln_f(plan, X, p + ".ln2", h, tag + "/ln2")
+            lin(plan, h, p + ".mlp.up_proj", g, R, I, H, pre_out=u, act=L.ACT_GELU)
+            lin(plan, g, p + ".mlp.down_proj", Xb, R, H, I, drop=self._drop(tag + "/mlpdrop", dp), residual=X, ldr=H)
+            return Xb
+
+        X = x_enc
+        stream_in = {}
+        for i in range(c.n_enc):
+            p, tag = f"encoder.{i}", f"enc{i}"
+            stream_in[tag] = X
+            Xa = self_block(fwd, X, p, tag, enc_flags)
+            X = mlp_block(fwd, Xa, p, tag)
+        enc_last = X
+        enc_out, context = buf("enc_out", (R, H)), buf("context", (R, H))
+        ln_f(fwd, X, "encoder_norm", enc_out, "encnorm")
+        lin(fwd, enc_out, "decoder_proj_context", context, R, H, H, residual=emb_enc, ldr=H)       # mm.py:292
+        Y = x_dec
+        for i in range(c.n_dec):
+            p, tag = f"decoder.{i}", f"dec{i}"
+            stream_in[tag] = Y
+            Ya = self_block(fwd, Y, p, tag, dec_flags)
+            hq, hc = buf(tag + "/hq", (R, H)), buf(tag + "/hc", (R, H))
+            qc, kvc, a2, Yb = buf(tag + "/qc", (R, H)), buf(tag + "/kvc", (R, 2 * H)), buf(tag + "/a2", (R, H)), buf(tag + "/yb", (R, H))
+            ln_f(fwd, Ya, p + ".query_norm", hq, tag + "/qn")
+            ln_f(fwd, context, p + ".context_norm", hc, tag + "/cn")
+            lin(fwd, hq, p + ".cross_attn.query", qc, R, H, H)
+            lin(fwd, hc, p + ".cross_attn.kv", kvc, R, 2 * H, H)
+            K.attn_fwd(attn_desc(tag + "/xa", qc, H, kvc, 2 * H, 0, H, a2, enc_flags), plan=fwd)   # xa_mask = encoder mask
+            lin(fwd, a2, p + ".cross_attn.out_proj", Yb, R, H, H, residual=Ya, ldr=H)
+            Y = mlp_block(fwd, Yb, p, tag)
+        dec_last = Y
+        ydec = buf("ydec", (R, H))                         # de-stitched: [M][B*T][H]
+        ln_f(fwd, Y, "decoder_norm", ydec, "decnorm", ds_L=Lq, ds_T=T)
+        for m, (mod, n) in enumerate(c.mods):
+            pred = buf(f"pred/{m}", (BT, n))
+            lin(fwd, ydec[m * BT:(m + 1) * BT], f"decoder_embeddings.{mod}.out", pred, BT, n, H)
+            K.masked_loss_fwd(c.loss_kind[mod], pred, self.b[f"tgt/{m}"], tokmask[:, m * T:], Lq, T, BT, n, loss_sum[m:m + 1],
+                              ws_loss, plan=fwd)
+        K.loss_finalize(loss_sum, count, M, self.b["loss"], self.b["inv_n"], plan=fwd)
+
+        # ============================================================ backward (segments fire DDP hooks)
+        bwd: List[Tuple[str, list]] = []
+        cur: list = []
+
+        def close_segment(name):
+            nonlocal cur
+            bwd.append((name, cur))
+            cur = []
+
+        dY = buf("d/stream", (R, H))
+        dydec = buf("d/ydec", (R, H))
+        t1, t2, dh_ = buf("d/t1", (R, H)), buf("d/t2", (R, H)), buf("d/h", (R, H))
+        du, dqkv, dctx = buf("d/u", (R, I)), buf("d/qkv", (R, 3 * H)), buf("d/ctx", (R, H))
+        for m, (mod, n) in enumerate(c.mods):
+            dpred = buf(f"d/pred/{m}", (BT, n))
+            K.masked_loss_bwd(c.loss_kind[mod], self.b[f"pred/{m}"], self.b[f"tgt/{m}"], tokmask[:, m * T:], Lq, T, BT, n,
+                              self.b["gout"], self.b["inv_n"], dpred, plan=cur)
+            dlin(cur, dpred, ydec[m * BT:(m + 1) * BT], f"decoder_embeddings.{mod}.out", BT, n, H, dX=dydec[m * BT:(m + 1) * BT])
+        ln_b(cur, dydec, dec_last, "decoder_norm", "decnorm", None, dY, ds_L=Lq, ds_T=T)
+        close_segment("head")
+
+        def mlp_back(plan, p, tag, X_in):
+            """X_in = the stream value that fed ln2 (= this block's residual input)."""
+            dYd = dY
+            if dp > 0:
+                K.dropout_apply(dY, t1, R, H, self._drop(tag + "/mlpdrop", dp), plan=plan)
+                dYd = t1
+            dlin(plan, dYd, self.b[tag + "/g"], p + ".mlp.down_proj", R, H, I, dX=du, act=L.ACT_GELU_GRAD, gradmul_pre=self.b[tag + "/u"])
+            dlin(plan, du, self.b[tag + "/h2"], p + ".mlp.up_proj", R, I, H, dX=dh_)
+            ln_b(plan, dh_, X_in, p + ".ln2", tag + "/ln2", dY, dY)
+
+        def self_back(plan, p, tag, X_in, flags):
+            dlin(plan, dY, self.b[tag + "/a"], p + ".attn.out_proj", R, H, H, dX=t2)
+            qkv = self.b[tag + "/qkv"]
+            K.attn_bwd(attn_desc(tag + "/sa", qkv, 3 * H, qkv, 3 * H, H, 2 * H, self.b[tag + "/a"], flags, d_o=t2, dq=dqkv, dkv=dqkv,
+                                 lddq=3 * H, lddkv=3 * H, dkoff=H, dvoff=2 * H), plan=plan)
+            dlin(plan, dqkv, self.b[tag + "/h1"], p + ".attn.qkv", R, 3 * H, H, dX=dh_)
+            ln_b(plan, dh_, X_in, p + ".ln1", tag + "/ln1", dY, dY)
+
+        first_ctx = True
+        for i in reversed(range(c.n_dec)):
+            p, tag = f"decoder.{i}", f"dec{i}"
+            mlp_back(cur, p, tag, self.b[tag + "/yb"])
+            # cross attention
+            dlin(cur, dY, self.b[tag + "/a2"], p + ".cross_attn.out_proj", R, H, H, dX=t2)
+            dqc, dkvc = dqkv[:, :H], None
+            dqc = buf("d/qc", (R, H)); dkvc = buf("d/kvc", (R, 2 * H))
+            K.attn_bwd(attn_desc(tag + "/xa", self.b[tag + "/qc"], H, self.b[tag + "/kvc"], 2 * H, 0, H, self.b[tag + "/a2"], enc_flags,
+                                 d_o=t2, dq=dqc, dkv=dkvc, lddq=H, lddkv=2 * H, dkoff=0, dvoff=H), plan=cur)
+            dlin(cur, dqc, self.b[tag + "/hq"], p + ".cross_attn.query", R, H, H, dX=dh_)
+            ln_b(cur, dh_, self.b[tag + "/xa"], p + ".query_norm", tag + "/qn", dY, dY)
+            dlin(cur, dkvc, self.b[tag + "/hc"], p + ".cross_attn.kv", R, 2 * H, H, dX=dh_)
+            ln_b(cur, dh_, context, p + ".context_norm", tag + "/cn", None if first_ctx else dctx, dctx)
+            first_ctx = False
+            self_back(cur, p, tag, stream_in[tag], dec_flags)
+            close_segment(p)
+        # dY = d(dec_tokens + dec_emb); dctx = d(context) = d(ctx_proj out) = d(encoder_emb) contribution
+        emb_tail = []
+        for m, (mod, n) in enumerate(c.mods):
+            pD = f"decoder_embeddings.{mod}.embedder"
+            K.stitch_bwd(dY, None, ts, keep0, self._drop(f"decoder/embdrop/{m}", dpe), buf(f"d/tok/decoder/{m}", (BT, H)),
+                         self.Gv(f"encoder_embeddings.{mod}.embedder.mod_emb.weight")[m], self.Gv(pD + ".pos_embed.weight"), False,
+                         B, T, Lq, m, H, c.max_F, ws_st, plan=emb_tail)
+        if c.n_dec == 0:
+            raise NotImplementedError("n_dec == 0")
+        dX = buf("d/xstream", (R, H))
+        dlin(cur, dctx, enc_out, "decoder_proj_context", R, H, H, dX=dh_)
+        ln_b(cur, dh_, enc_last, "encoder_norm", "encnorm", None, dX)
+        close_segment("bridge")
+        dY_save = dY
+        dY = dX      # the helpers below close over `dY`: rebind for the encoder stream
+
+        def mlp_back_e(plan, p, tag, X_in):
+            dYd = dX
+            if dp > 0:
+                K.dropout_apply(dX, t1, R, H, self._drop(tag + "/mlpdrop", dp), plan=plan)
+                dYd = t1
+            dlin(plan, dYd, self.b[tag + "/g"], p + ".mlp.down_proj", R, H, I, dX=du, act=L.ACT_GELU_GRAD, gradmul_pre=self.b[tag + "/u"])
+            dlin(plan, du, self.b[tag + "/h2"], p + ".mlp.up_proj", R, I, H, dX=dh_)
+            ln_b(plan, dh_, X_in, p + ".ln2", tag + "/ln2", dX, dX)
+
+        def self_back_e(plan, p, tag, X_in, flags):
+            dlin(plan, dX, self.b[tag + "/a"], p + ".attn.out_proj", R, H, H, dX=t2)
+            qkv = self.b[tag + "/qkv"]
+            K.attn_bwd(attn_desc(tag + "/sa", qkv, 3 * H, qkv, 3 * H, H, 2 * H, self.b[tag + "/a"], flags, d_o=t2, dq=dqkv, dkv=dqkv,
+                                 lddq=3 * H, lddkv=3 * H, dkoff=H, dvoff=2 * H), plan=plan)
+            dlin(plan, dqkv, self.b[tag + "/h1"], p + ".attn.qkv", R, 3 * H, H, dX=dh_)
+            ln_b(plan, dh_, X_in, p + ".ln1", tag + "/ln1", dX, dX)
+
+        for i in reversed(range(c.n_enc)):
+            p, tag = f"encoder.{i}", f"enc{i}"
+            mlp_back_e(cur, p, tag, self.b[tag + "/xa"])
+            self_back_e(cur, p, tag, stream_in[tag], enc_flags)
+            close_segment(p)
+        cur.extend(emb_tail)
+        for m, (mod, n) in enumerate(c.mods):
+            pE = f"encoder_embeddings.{mod}.embedder"
+            K.stitch_bwd(dX, dctx, ts, keep0, self._drop(f"encoder/embdrop/{m}", dpe), buf(f"d/tok/encoder/{m}", (BT, H)),
+                         self.Gv(pE + ".mod_emb.weight")[m], self.Gv(pE + ".pos_embed.weight"), True,
+                         B, T, Lq, m, H, c.max_F, ws_st, plan=cur)
+        for side in ("decoder", "encoder"):
+            for m, (mod, n) in enumerate(c.mods):
+                p = f"{side}_embeddings.{mod}.embedder"
+                n2 = n * c.mult
+                dz = buf(f"d/z/{m}", (BT, n2))
+                dlin(cur, self.b[f"d/tok/{side}/{m}"], self.b[f"{side}/a/{m}"], p + ".projection", BT, H, n2, dX=dz,
+                     act=L.ACT_SOFTSIGN_GRAD, act_scale=c.embed_scale, gradmul_pre=self.b[f"{side}/z/{m}"])
+                dlin(cur, dz, self.b[f"in/{m}"], p + ".token_embed", BT, n2, n)
+        close_segment("embed")
+        plan = dict(fwd=fwd, bwd=bwd, B=B, T=T, training=bool(training), M=M, R=R, BT=BT)
+        self.plans[key] = plan
+        return plan
+
+    # ------------------------------------------------------------------ data in
+    def load_inputs(self, B, T, inputs, targets, masks, ts, attn):
+        """Copy one batch into the static input buffers (device tensors or host tensors)."""
+        for m in range(len(self.cfg.mods)):
+            self.b[f"in/{m}"].view(B, T, -1).copy_(inputs[m], non_blocking=True)
+            self.b[f"tgt/{m}"].view(B, T, -1).copy_(targets[m], non_blocking=True)
+            self.b[f"mask/{m}"].copy_(masks[m], non_blocking=True)
+        self.b["ts"].copy_(ts, non_blocking=True)
+        self.b["attn"].copy_(attn, non_blocking=True)
+
+    # ------------------------------------------------------------------ run
+    def forward(self, B, T, inputs, targets, masks, ts, attn, training=True, anchor=None):
+        plan = self._plan(B, T, training)
+        self.load_inputs(B, T, inputs, targets, masks, ts, attn)
+        if training and (self.cfg.dropout > 0 or self.cfg.embed_dropout > 0):
+            K.rng_advance(self.rng)
+        K.run_plan(plan["fwd"])
+        self._token += 1
+        self._fwd_token = self._token
+        self._last = plan
+        M = plan["M"]
+        out = dict(mod_loss=[self.b["loss_sum"][m].clone() for m in range(M)],
+                   mod_n=[self.b["count"][m].clone() for m in range(M)],
+                   preds=[self.b[f"pred/{m}"].view(B, T, -1) for m in range(M)])
+        if anchor is not None and torch.is_grad_enabled() and anchor.requires_grad:
+            out["loss"] = _StepFn.apply(anchor, self, self._token)
+        else:
+            out["loss"] = self.b["loss"].clone().reshape(())
+        return out
+
+    def backward(self, grad_out=None, token=None):
+        if token is not None and token != self._fwd_token:
+            raise RuntimeError("backward() must follow the forward() that produced this loss: the engine keeps one "
+                               "set of activation buffers")
+        if grad_out is None:
+            self.b["gout"].fill_(1.0)
+        else:
+            self.b["gout"].copy_(grad_out.reshape(1).to(torch.float32))
+        accumulate_into = None
+        first = next(iter(self.params.values()), None)
+        if first is not None and first.grad is not None:
+            accumulate_into = self.G.clone()               # caller did not zero_grad(): keep torch's += semantics
+        for name, seg in self._last["bwd"]:
+            K.run_plan(seg)
+            if accumulate_into is None:
+                for hook in self.grad_ready_hooks:
+                    hook(name)
+        if accumulate_into is not None:
+            self.G.add_(accumulate_into)
+            for hook in self.grad_ready_hooks:
+                for name, _ in self._last["bwd"]:
+                    hook(name)
+        for name, p in self.params.items():
+            if p.grad is None or p.grad.data_ptr() != self.Gv(name).data_ptr():
+                p.grad = self.Gv(name)
+
+    def segment_range(self, name):
+        for n, s, e in self.layout.segments:
+            if n == name:
+                return s, e
+        raise KeyError(name)

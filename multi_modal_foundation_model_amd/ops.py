@@ -1,0 +1,153 @@
+"""Tensor-level wrappers over the C-ABI.  Each op either runs now (on torch's current stream) or,
+when `plan` is a list, is appended to it as a pre-bound `(cfunc, args)` pair: the engine builds such
+a plan once per batch shape and replays it every step (no per-step Python marshalling, and the
+replay is hipGraph-capturable because no call allocates or synchronises)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def run_plan(plan, stream=None):
+    st = _stream() if stream is None else stream
+    for fn, args, _keep in plan:
+        rc = fn(*args, st)
+        if rc:
+            L.check(rc, fn.__name__)
+
+
+def _emit(plan, fn, args, keep=()):
+    if plan is None:
+        L.check(fn(*args, _stream()), fn.__name__)
+    else:
+        plan.append((fn, args, keep))
+
+
+def P(t):
+    return None if t is None else t.data_ptr()
+
+
+def dt(t):
+    if t.dtype == torch.float32:
+        return L.F32
+    if t.dtype == torch.bfloat16:
+        return L.BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def dropout(state, site, p):
+    if state is None or p <= 0:
+        return L.NO_DROP
+    return L.Dropout(state.data_ptr(), site, float(p))
+
+
+def gemm(A, B, Cout, M, N, K, *, lda, ldb, ldc, a_kcontig=1, b_kcontig=1, bias=None, pre_out=None, act=0,
+         act_scale=1.0, gradmul_pre=None, drop=None, residual=None, ldr=0, splits=1, kchunk=0, slab_stride=0,
+         dtype=None, c_f32=0, plan=None):
+    d = L.GemmDesc()
+    d.dtype = dt(A) if dtype is None else dtype
+    d.c_f32 = c_f32
+    d.A, d.B, d.C = P(A), P(B), P(Cout)
+    d.M, d.N, d.K, d.lda, d.ldb, d.ldc = M, N, K, lda, ldb, ldc
+    d.a_kcontig, d.b_kcontig = a_kcontig, b_kcontig
+    d.splits, d.kchunk, d.slab_stride = splits, kchunk, slab_stride
+    d.bias, d.pre_out, d.act, d.act_scale, d.gradmul_pre = P(bias), P(pre_out), act, act_scale, P(gradmul_pre)
+    d.drop = drop if drop is not None else L.NO_DROP
+    d.residual, d.ldr = P(residual), ldr
+    _emit(plan, L.lib().mmfm_gemm, (C.byref(d),), keep=(d,))
+
+
+def reduce_slabs(dst, src, n, nslabs, stride, accumulate=False, plan=None):
+    _emit(plan, L.lib().mmfm_reduce_slabs, (P(dst), P(src), n, nslabs, stride, int(accumulate)))
+
+
+def colsum(x, R, N, ld, out, ws, accumulate=False, plan=None):
+    _emit(plan, L.lib().mmfm_colsum, (dt(x), P(x), R, N, ld, P(out), int(accumulate), P(ws), ws.numel() * ws.element_size()))
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, R, H, eps=1e-5, ds_L=0, ds_T=0, plan=None):
+    _emit(plan, L.lib().mmfm_layernorm_fwd, (dt(x), P(x), P(gamma), P(beta), P(y), P(mean), P(rstd), R, H, eps, ds_L, ds_T))
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, R, H, ws, accumulate=False, ds_L=0, ds_T=0, plan=None):
+    _emit(plan, L.lib().mmfm_layernorm_bwd, (dt(x), P(dy), P(x), P(mean), P(rstd), P(gamma), P(dres), P(dx), P(dgamma),
+                                             P(dbeta), int(accumulate), R, H, ds_L, ds_T, P(ws), ws.numel() * ws.element_size()))
+
+
+def attn_desc(dtype, B, heads, Lq, Lk, dh, q, k, v, ldq, ldk, ldv, o, ldo, lse, keypad, mod_id, flags, scale,
+              drop_p=None, drop_o=None, d_o=None, lddo=0, dq=None, dk=None, dv=None, lddq=0, lddk=0, lddv=0):
+    d = L.AttnDesc()
+    d.dtype, d.B, d.heads, d.Lq, d.Lk, d.dh = dtype, B, heads, Lq, Lk, dh
+    d.q, d.k, d.v, d.ldq, d.ldk, d.ldv = q, k, v, ldq, ldk, ldv
+    d.o, d.ldo, d.lse, d.keypad, d.mod_id, d.flags, d.scale = o, ldo, P(lse), P(keypad), P(mod_id), flags, scale
+    d.drop_p = drop_p if drop_p is not None else L.NO_DROP
+    d.drop_o = drop_o if drop_o is not None else L.NO_DROP
+    d.d_o, d.lddo, d.dq, d.dk, d.dv, d.lddq, d.lddk, d.lddv = d_o, lddo, dq, dk, dv, lddq, lddk, lddv
+    return d
+
+
+def attn_fwd(desc, plan=None):
+    _emit(plan, L.lib().mmfm_attn_fwd, (C.byref(desc),), keep=(desc,))
+
+
+def attn_bwd(desc, plan=None):
+    _emit(plan, L.lib().mmfm_attn_bwd, (C.byref(desc),), keep=(desc,))
+
+
+def mask_prep(B, T, masks, strides, attn, channels, tokmask, keypad, keep0, mod_id, count, plan=None):
+    M = len(masks)
+    src = (C.c_void_p * M)(*[m.data_ptr() for m in masks])
+    st = (C.c_int64 * M)(*strides)
+    ch = (C.c_int64 * M)(*channels)
+    _emit(plan, L.lib().mmfm_mask_prep, (B, T, M, src, st, P(attn), ch, P(tokmask), P(keypad), P(keep0), P(mod_id), P(count)),
+          keep=(src, st, ch))
+
+
+def stitch_fwd(tok, mod_row, pos, ts, keep0, x, emb, B, T, Lseq, m, H, max_F, plan=None):
+    _emit(plan, L.lib().mmfm_stitch_fwd, (dt(tok), P(tok), P(mod_row), P(pos), P(ts), P(keep0), P(x), P(emb), B, T, Lseq, m, H, max_F))
+
+
+def stitch_bwd(dx, dextra, ts, keep0, drop, d_tok, d_mod_row, d_pos, accumulate, B, T, Lseq, m, H, max_F, ws, plan=None):
+    _emit(plan, L.lib().mmfm_stitch_bwd, (dt(dx), P(dx), P(dextra), P(ts), P(keep0), drop if drop is not None else L.NO_DROP,
+                                          P(d_tok), P(d_mod_row), P(d_pos), int(accumulate), B, T, Lseq, m, H, max_F, P(ws),
+                                          ws.numel() * ws.element_size()))
+
+
+def masked_loss_fwd(kind, pred, target, rowmask, mask_ld, T, R, N, loss_sum, ws, plan=None):
+    _emit(plan, L.lib().mmfm_masked_loss_fwd, (dt(pred), kind, P(pred), P(target), P(rowmask), mask_ld, T, R, N, P(loss_sum), P(ws),
+                                               ws.numel() * ws.element_size()))
+
+
+def loss_finalize(loss_sum, count, M, loss, inv_n, plan=None):
+    _emit(plan, L.lib().mmfm_loss_finalize, (P(loss_sum), P(count), M, P(loss), P(inv_n)))
+
+
+def masked_loss_bwd(kind, pred, target, rowmask, mask_ld, T, R, N, grad_out, inv_n, dpred, plan=None):
+    _emit(plan, L.lib().mmfm_masked_loss_bwd, (dt(pred), kind, P(pred), P(target), P(rowmask), mask_ld, T, R, N, P(grad_out), P(inv_n), P(dpred)))
+
+
+def dropout_apply(src, dst, R, N, drop, plan=None):
+    _emit(plan, L.lib().mmfm_dropout_apply, (dt(src), P(src), P(dst), R, N, drop))
+
+
+def cast_bf16(src, dst, n, plan=None):
+    _emit(plan, L.lib().mmfm_cast_f32_to_bf16, (P(src), P(dst), n))
+
+
+def adamw_step(p, g, m, v, p_bf16, n, hyper, plan=None):
+    _emit(plan, L.lib().mmfm_adamw_step, (P(p), P(g), P(m), P(v), P(p_bf16), n, P(hyper)))
+
+
+def rng_seed(state, seed, plan=None):
+    _emit(plan, L.lib().mmfm_rng_seed, (P(state), int(seed) & (2 ** 64 - 1)))
+
+
+def rng_advance(state, plan=None):
+    _emit(plan, L.lib().mmfm_rng_advance, (P(state),))

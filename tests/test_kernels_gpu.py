@@ -1,0 +1,382 @@
+"""Per-kernel parity: every C-ABI entry point against a plain torch fp32 reference of the same op
+(the oracle's functions where one exists).  Runs on the MI355X only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz
+from oracle import mm_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from multi_modal_foundation_model_amd import _lib as L, ops as K
+    L.check(L.lib().mmfm_device_check(0), "device_check")
+    return K
+
+
+def dev(t):
+    return t.cuda()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def close(a, b, rtol=2e-5, atol=2e-5, msg=""):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), f"{msg}: max abs err {err:.3e} (ref max {ref:.3e})"
+
+
+# ------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(200, 256, 256), (333, 668, 1336), (3200, 768, 256), (300, 2, 256), (100, 4, 2), (64, 256, 4), (1600, 1336, 668)])
+def test_gemm_linear_forward(ops, M, N, K):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3)
+    y = torch.empty(M, N, device="cuda")
+    ops.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b)
+    close(y, x.double() @ w.double().T + b.double(), msg=f"linear {M}x{N}x{K}")
+
+
+def test_gemm_epilogues(ops):
+    M, N, K = 500, 512, 256
+    x, w, b, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    y, pre = torch.empty(M, N, device="cuda"), torch.empty(M, N, device="cuda")
+    ops.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b, pre_out=pre, act=1)
+    u = x @ w.T + b
+    close(pre, u, msg="pre_out")
+    close(y, torch.nn.functional.gelu(u), msg="gelu")
+    ops.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b, act=2, act_scale=1.5)
+    close(y, O.softsign(u) * 1.5, msg="softsign")
+    ops.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b, residual=res, ldr=N)
+    close(y, u + res, msg="residual")
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 256, 512), (450, 668, 256), (200, 1336, 256), (128, 2, 4)])
+def test_gemm_dx_and_actgrad(ops, M, N, K):
+    """dX = dY[M,K] @ W[K,N]  (W is an nn.Linear weight [out=K, in=N]); optional act' multiply."""
+    dy, w, pre = rnd(M, K, seed=5), rnd(K, N, seed=6, scale=K ** -0.5), rnd(M, N, seed=7)
+    dx = torch.empty(M, N, device="cuda")
+    ops.gemm(dy, w, dx, M, N, K, lda=K, ldb=N, ldc=N, b_kcontig=0)
+    close(dx, dy.double() @ w.double(), msg="dX")
+    ops.gemm(dy, w, dx, M, N, K, lda=K, ldb=N, ldc=N, b_kcontig=0, act=3, gradmul_pre=pre)
+    pr = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(pr).sum().backward()
+    close(dx, (dy @ w) * pr.grad, msg="dX*gelu'")
+    ops.gemm(dy, w, dx, M, N, K, lda=K, ldb=N, ldc=N, b_kcontig=0, act=4, act_scale=2.0, gradmul_pre=pre)
+    close(dx, (dy @ w) * 2.0 / (1 + pre.abs()) ** 2, msg="dX*softsign'")
+
+
+@pytest.mark.parametrize("R,N,K,splits", [(3200, 256, 256, 8), (1000, 668, 256, 4), (777, 1336, 668, 3), (640, 2, 256, 2), (3200, 256, 512, 1)])
+def test_gemm_dw_splitk(ops, R, N, K, splits):
+    """dW[N,K] = dY[R,N]^T @ X[R,K] with split-K slabs + deterministic reduce."""
+    dy, x = rnd(R, N, seed=8), rnd(R, K, seed=9)
+    ref = dy.double().T @ x.double()
+    dw = torch.empty(N, K, device="cuda")
+    if splits == 1:
+        ops.gemm(dy, x, dw, N, K, R, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0)
+    else:
+        kchunk = ((R + splits - 1) // splits + 31) // 32 * 32
+        splits = (R + kchunk - 1) // kchunk
+        slabs = torch.full((splits, N, K), float("nan"), device="cuda")
+        ops.gemm(dy, x, slabs, N, K, R, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0, splits=splits, kchunk=kchunk, slab_stride=N * K)
+        ops.reduce_slabs(dw, slabs, N * K, splits, N * K)
+    close(dw, ref, rtol=1e-4, atol=1e-3 * R ** 0.5 / 30, msg="dW")
+
+
+def test_colsum(ops):
+    for R, N in [(3200, 256), (1001, 668), (64, 2)]:
+        x = rnd(R, N, seed=10)
+        out = torch.empty(N, device="cuda")
+        ws = torch.empty(64 * N + 16, device="cuda")
+        ops.colsum(x, R, N, N, out, ws)
+        close(out, x.double().sum(0), atol=1e-3, msg="colsum")
+        ops.colsum(x, R, N, N, out, ws, accumulate=True)
+        close(out, 2 * x.double().sum(0), atol=2e-3, msg="colsum acc")
+
+
+def test_gemm_argument_errors(ops):
+    from multi_modal_foundation_model_amd._lib import MmfmError
+    x = rnd(8, 8)
+    with pytest.raises(MmfmError):
+        ops.gemm(x, x, x, 8, 8, 8, lda=4, ldb=8, ldc=8)
+    with pytest.raises(MmfmError):
+        ops.gemm(x, x, x, 8, 8, 8, lda=8, ldb=8, ldc=8, act=3)
+
+
+# ------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("R,H", [(3200, 256), (33, 32), (77, 512), (5, 1024)])
+def test_layernorm(ops, R, H):
+    x, g, b, dy, dres = rnd(R, H, seed=1, scale=2.0), rnd(H, seed=2), rnd(H, seed=3), rnd(R, H, seed=4), rnd(R, H, seed=5)
+    y, mean, rstd = torch.empty_like(x), torch.empty(R, device="cuda"), torch.empty(R, device="cuda")
+    ops.layernorm_fwd(x, g, b, y, mean, rstd, R, H)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (H,), gr, br, 1e-5)
+    close(y, yr, msg="ln fwd")
+    close(mean, x.mean(-1), msg="mean")
+    yr.backward(dy)
+    dx, dg, db = torch.empty_like(x), torch.empty(H, device="cuda"), torch.empty(H, device="cuda")
+    ws = torch.empty(1024 * 2 * H, device="cuda")
+    ops.layernorm_bwd(dy, x, mean, rstd, g, dres, dx, dg, db, R, H, ws)
+    close(dx, xr.grad + dres, rtol=1e-4, atol=1e-4, msg="ln dx")
+    close(dg, gr.grad, rtol=1e-4, atol=1e-3, msg="ln dgamma")
+    close(db, br.grad, rtol=1e-4, atol=1e-3, msg="ln dbeta")
+    ops.layernorm_bwd(dy, x, mean, rstd, g, None, dx, dg, db, R, H, ws, accumulate=True)
+    close(dx, xr.grad, rtol=1e-4, atol=1e-4, msg="ln dx (no dres)")
+    close(dg, 2 * gr.grad, rtol=1e-4, atol=2e-3, msg="ln dgamma acc")
+
+
+def test_layernorm_destitch(ops):
+    B, M, T, H = 3, 2, 5, 32
+    L = M * T
+    x, g, b = rnd(B * L, H, seed=1), rnd(H, seed=2), rnd(H, seed=3)
+    y, mean, rstd = torch.empty_like(x), torch.empty(B * L, device="cuda"), torch.empty(B * L, device="cuda")
+    ops.layernorm_fwd(x, g, b, y, mean, rstd, B * L, H, ds_L=L, ds_T=T)
+    ref = torch.nn.functional.layer_norm(x, (H,), g, b, 1e-5).view(B, M, T, H).permute(1, 0, 2, 3).reshape(B * L, H)
+    close(y, ref, msg="destitched ln")
+    dy = rnd(B * L, H, seed=4)          # laid out [M][B*T][H]
+    dx, dg, db = torch.empty_like(x), torch.empty(H, device="cuda"), torch.empty(H, device="cuda")
+    ws = torch.empty(1024 * 2 * H, device="cuda")
+    ops.layernorm_bwd(dy, x, mean, rstd, g, None, dx, dg, db, B * L, H, ws, ds_L=L, ds_T=T)
+    xr = x.clone().requires_grad_(True)
+    torch.nn.functional.layer_norm(xr, (H,), g, b, 1e-5).backward(dy.view(M, B, T, H).permute(1, 0, 2, 3).reshape(B * L, H))
+    close(dx, xr.grad, rtol=1e-4, atol=1e-4, msg="destitched ln bwd")
+
+
+# ------------------------------------------------------------------------------------ attention
+def ref_attention(q, k, v, mask, scale):
+    s = (q @ k.transpose(-1, -2)) * scale
+    s = s.masked_fill(~mask[:, None], float("-inf"))
+    return torch.softmax(s, -1) @ v
+
+
+@pytest.mark.parametrize("B,heads,L,dh,flags", [(2, 8, 200, 32, 1), (2, 8, 200, 32, 0), (3, 4, 16, 8, 1), (2, 4, 16, 8, 2),
+                                                (2, 4, 16, 8, 4), (2, 2, 70, 16, 1), (1, 8, 100, 64, 1)])
+def test_attention_fwd_bwd(ops, B, heads, L, dh, flags):
+    from multi_modal_foundation_model_amd import _lib as Lb
+    H = heads * dh
+    qkv = rnd(B * L, 3 * H, seed=1)
+    d_o = rnd(B * L, H, seed=2)
+    keypad = torch.ones(B, L, dtype=torch.uint8)
+    keypad[0, L - 3:] = 0
+    if B > 1:
+        keypad[1, L // 2: L // 2 + 2] = 0
+    mod_id = (torch.arange(L) >= L // 2).to(torch.uint8)
+    kp, mi = keypad.cuda(), mod_id.cuda()
+    o, lse = torch.empty(B * L, H, device="cuda"), torch.empty(B, heads, L, device="cuda")
+    dqkv = torch.full((B * L, 3 * H), float("nan"), device="cuda")
+    scale = 1.0 / math.sqrt(dh)
+    es = 4
+    base = qkv.data_ptr()
+    desc = ops.attn_desc(Lb.F32, B, heads, L, L, dh, base, base + H * es, base + 2 * H * es, 3 * H, 3 * H, 3 * H, o.data_ptr(), H, lse, kp, mi,
+                         flags, scale, d_o=d_o.data_ptr(), lddo=H, dq=dqkv.data_ptr(), dk=dqkv.data_ptr() + H * es,
+                         dv=dqkv.data_ptr() + 2 * H * es, lddq=3 * H, lddk=3 * H, lddv=3 * H)
+    ops.attn_fwd(desc)
+    ops.attn_bwd(desc)
+    # reference
+    kpb = kp.bool()
+    if flags & 2:
+        m = torch.tril(torch.ones(L, L, dtype=torch.bool, device="cuda"))[None].expand(B, L, L)
+    else:
+        m = kpb[:, None, :].expand(B, L, L)
+    if flags & 1:
+        m = m | torch.eye(L, dtype=torch.bool, device="cuda")[None]
+    if flags & 4:
+        m = m | (mi[None, :, None] != mi[None, None, :])
+    x = qkv.clone().requires_grad_(True)
+    q, k, v = [t.view(B, L, heads, dh).transpose(1, 2) for t in x.split(H, dim=1)]
+    oref = ref_attention(q, k, v, m, scale).transpose(1, 2).reshape(B * L, H)
+    close(o, oref, rtol=1e-4, atol=2e-5, msg="attn fwd")
+    s = (q @ k.transpose(-1, -2)) * scale
+    lref = torch.logsumexp(s.masked_fill(~m[:, None], float("-inf")), -1)
+    close(lse, lref, rtol=1e-5, atol=1e-4, msg="lse")
+    oref.backward(d_o)
+    close(dqkv, x.grad, rtol=1e-3, atol=5e-5, msg="attn bwd")
+
+
+def test_attention_cross_shapes(ops):
+    """Lq != Lk (no DIAG): cross attention over a longer context."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    B, heads, Lq, Lk, dh = 2, 4, 40, 72, 32
+    H = heads * dh
+    q, kv, d_o = rnd(B * Lq, H, seed=1), rnd(B * Lk, 2 * H, seed=2), rnd(B * Lq, H, seed=3)
+    kp = torch.ones(B, Lk, dtype=torch.uint8)
+    kp[1, 60:] = 0
+    kp = kp.cuda()
+    o, lse = torch.empty(B * Lq, H, device="cuda"), torch.empty(B, heads, Lq, device="cuda")
+    dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+    desc = ops.attn_desc(Lb.F32, B, heads, Lq, Lk, dh, q.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * 4, H, 2 * H, 2 * H, o.data_ptr(), H, lse,
+                         kp, None, 0, dh ** -0.5, d_o=d_o.data_ptr(), lddo=H, dq=dq.data_ptr(), dk=dkv.data_ptr(),
+                         dv=dkv.data_ptr() + H * 4, lddq=H, lddk=2 * H, lddv=2 * H)
+    ops.attn_fwd(desc)
+    ops.attn_bwd(desc)
+    qr, kvr = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    Q = qr.view(B, Lq, heads, dh).transpose(1, 2)
+    K_, V_ = [t.view(B, Lk, heads, dh).transpose(1, 2) for t in kvr.split(H, dim=1)]
+    oref = ref_attention(Q, K_, V_, kp.bool()[:, None, :].expand(B, Lq, Lk), dh ** -0.5).transpose(1, 2).reshape(B * Lq, H)
+    close(o, oref, rtol=1e-4, atol=2e-5, msg="xattn fwd")
+    oref.backward(d_o)
+    close(dq, qr.grad, rtol=1e-3, atol=5e-5, msg="xattn dq")
+    close(dkv, kvr.grad, rtol=1e-3, atol=5e-5, msg="xattn dkv")
+
+
+def test_attention_dropout_consistency(ops):
+    """Dropout masks are regenerated in the backward: check dV against the forward's own mask by
+    linearity: with q=k=0 all probabilities are uniform, so O = mean over kept keys of V/(1-p)."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    B, heads, L, dh, p = 2, 4, 64, 32, 0.4
+    H = heads * dh
+    qkv = torch.zeros(B * L, 3 * H, device="cuda")
+    qkv[:, 2 * H:] = 1.0                                    # V = 1  => O[q] = kept_fraction/(1-p)
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 1234)
+    kp = torch.ones(B, L, dtype=torch.uint8, device="cuda")
+    o, lse = torch.empty(B * L, H, device="cuda"), torch.empty(B, heads, L, device="cuda")
+    d_o = torch.ones(B * L, H, device="cuda")
+    dqkv = torch.empty(B * L, 3 * H, device="cuda")
+    base, es = qkv.data_ptr(), 4
+    desc = ops.attn_desc(Lb.F32, B, heads, L, L, dh, base, base + H * es, base + 2 * H * es, 3 * H, 3 * H, 3 * H, o.data_ptr(), H, lse, kp, None, 0,
+                         dh ** -0.5, drop_p=ops.dropout(state, 7, p), d_o=d_o.data_ptr(), lddo=H, dq=dqkv.data_ptr(),
+                         dk=dqkv.data_ptr() + H * es, dv=dqkv.data_ptr() + 2 * H * es, lddq=3 * H, lddk=3 * H, lddv=3 * H)
+    ops.attn_fwd(desc)
+    o1 = o.clone()
+    ops.attn_fwd(desc)
+    assert torch.equal(o, o1), "same state/site must give the same mask"
+    frac = o.view(B, L, heads, dh)[..., 0] * (1 - p)            # kept fraction per (b,q,h)
+    assert abs(frac.mean().item() - (1 - p)) < 0.02
+    assert frac.std().item() > 0.01
+    ops.attn_bwd(desc)
+    dv = dqkv[:, 2 * H:].view(B, L, heads, dh)[..., 0]          # dV[k] = sum_q keep(q,k)/((1-p) L)
+    # sum_k dV[k] == sum_q O[q]  (both count kept (q,k) pairs)
+    close(dv.sum(1), o.view(B, L, heads, dh)[..., 0].sum(1), rtol=1e-4, atol=1e-3, msg="fwd/bwd dropout mask agree")
+    ops.rng_advance(state)
+    ops.attn_fwd(desc)
+    assert not torch.equal(o, o1), "advancing the RNG state must change the mask"
+
+
+# ------------------------------------------------------------------------------------ masks / stitch / loss
+def test_mask_prep_bit_exact_vs_reference_fixture(ops):
+    z, cases = load_npz("mask_index_ops.npz")
+    attn = torch.from_numpy(z["attn"])
+    B, T = attn.shape
+    for key in cases:
+        ms = [torch.from_numpy(z[f"{key}/in_mask/{m}"]) for m in ("ap", "behavior")]
+        # feed un-anded masks with a channel dim to exercise stride + the '& attn' (mm.py:270)
+        full = [m[:, :, None].repeat(1, 1, 3).contiguous().cuda() for m in ms]
+        L = 2 * T
+        tok, kpd = torch.empty(B, L, dtype=torch.uint8, device="cuda"), torch.empty(B, L, dtype=torch.uint8, device="cuda")
+        keep0, mod = torch.empty(L, dtype=torch.uint8, device="cuda"), torch.empty(L, dtype=torch.uint8, device="cuda")
+        cnt = torch.empty(2, dtype=torch.int64, device="cuda")
+        ops.mask_prep(B, T, full, [3, 3], attn.cuda(), [5, 2], tok, kpd, keep0, mod, cnt)
+        enc_mask = torch.from_numpy(z[f"{key}/enc_mask"])
+        np.testing.assert_array_equal(tok.cpu().numpy(), enc_mask.numpy().astype(np.uint8))
+        np.testing.assert_array_equal(kpd.cpu().numpy(), torch.cat([attn, attn], 1).numpy().astype(np.uint8))
+        np.testing.assert_array_equal(mod.cpu().numpy(), z[f"{key}/enc_mod_mask"][0].astype(np.uint8))
+        np.testing.assert_array_equal(keep0.cpu().numpy(), (enc_mask[0] != 1).numpy().astype(np.uint8))
+        assert cnt.tolist() == [int(enc_mask[:, :T].sum()) * 5, int(enc_mask[:, T:].sum()) * 2]
+        # zeroed-token positions == the reference's (sample-0 quirk)
+        xs = [torch.from_numpy(z[f"{key}/in_x/{m}"]) for m in ("ap", "behavior")]
+        toks = torch.cat(xs, 1) * keep0.cpu()[None, :, None]
+        np.testing.assert_array_equal(toks.numpy(), z[f"{key}/enc_tokens"])
+
+
+def test_stitch_fwd_bwd(ops):
+    B, T, M, H, max_F = 5, 7, 2, 32, 9
+    L = M * T
+    g = torch.Generator().manual_seed(3)
+    ts = torch.randint(0, max_F, (B, T), generator=g).cuda()
+    keep0 = (torch.rand(L, generator=g) > 0.3).to(torch.uint8).cuda()
+    x, emb = torch.zeros(B, L, H, device="cuda"), torch.zeros(B, L, H, device="cuda")
+    toks = [rnd(B * T, H, seed=10 + m).requires_grad_(True) for m in range(M)]
+    mods = [rnd(H, seed=20 + m).requires_grad_(True) for m in range(M)]
+    poss = [rnd(max_F, H, seed=30 + m).requires_grad_(True) for m in range(M)]
+    for m in range(M):
+        ops.stitch_fwd(toks[m].detach(), mods[m].detach(), poss[m].detach(), ts, keep0, x, emb, B, T, L, m, H, max_F)
+    e_ref = torch.cat([mods[m][None, None, :] + poss[m][ts] for m in range(M)], 1)
+    x_ref = torch.cat([t.view(B, T, H) for t in toks], 1) * keep0[None, :, None] + e_ref
+    close(emb, e_ref, msg="emb")
+    close(x, x_ref, msg="x")
+    dx, dextra = rnd(B, L, H, seed=40), rnd(B, L, H, seed=41)
+    (x_ref * dx + e_ref * dextra).sum().backward()
+    ws = torch.empty(64 * (max_F + 1) * H * 8, device="cuda")
+    for m in range(M):
+        d_tok, d_mod, d_pos = torch.empty(B * T, H, device="cuda"), torch.empty(H, device="cuda"), torch.empty(max_F, H, device="cuda")
+        ops.stitch_bwd(dx, dextra, ts, keep0, None, d_tok, d_mod, d_pos, False, B, T, L, m, H, max_F, ws)
+        close(d_tok, toks[m].grad, msg="d_tok")
+        close(d_mod, mods[m].grad, atol=1e-4, msg="d_mod")
+        close(d_pos, poss[m].grad, atol=1e-4, msg="d_pos")
+
+
+@pytest.mark.parametrize("kind,N", [(0, 668), (1, 2), (0, 12)])
+def test_masked_loss(ops, kind, N):
+    B, T = 6, 10
+    R = B * T
+    pred = rnd(R, N, seed=1, scale=0.5)
+    tgt = torch.poisson(torch.full((R, N), 0.3)).cuda() if kind == 0 else rnd(R, N, seed=2)
+    M = 2
+    tokmask = (torch.rand(B, M * T) < 0.4).to(torch.uint8).cuda()
+    rowmask = tokmask[:, T:]                                  # modality 1's slice: mask_ld = M*T
+    out, ws = torch.empty(1, device="cuda"), torch.empty(1024, device="cuda")
+    ops.masked_loss_fwd(kind, pred, tgt, rowmask, M * T, T, R, N, out, ws)
+    pr = pred.clone().requires_grad_(True)
+    el = (torch.exp(pr) - tgt * pr) if kind == 0 else (pr - tgt) ** 2
+    mk = rowmask.reshape(R, 1).float()
+    ref = (el * mk).sum()
+    close(out[0], ref, rtol=1e-5, atol=1e-3, msg="loss sum")
+    cnt = torch.tensor([int(rowmask.sum()) * N, 7], dtype=torch.int64, device="cuda")
+    sums = torch.stack([out[0], torch.tensor(3.0, device="cuda")])
+    loss, inv_n = torch.empty(1, device="cuda"), torch.empty(1, device="cuda")
+    ops.loss_finalize(sums, cnt, 2, loss, inv_n)
+    n = int(cnt.sum())
+    close(loss[0], (ref + 3.0) / n, rtol=1e-5, msg="loss")
+    gout = torch.tensor([0.5], device="cuda")
+    dpred = torch.empty_like(pred)
+    ops.masked_loss_bwd(kind, pred, tgt, rowmask, M * T, T, R, N, gout, inv_n, dpred)
+    (0.5 * ref / n).backward()
+    close(dpred, pr.grad, rtol=1e-5, atol=1e-8, msg="dpred")
+    # nothing masked -> 0/0 = NaN like the reference (mm.py:237)
+    ops.loss_finalize(torch.zeros(2, device="cuda"), torch.zeros(2, dtype=torch.int64, device="cuda"), 2, loss, inv_n)
+    assert torch.isnan(loss[0])
+
+
+# ------------------------------------------------------------------------------------ optimiser / dropout
+def test_adamw_matches_torch(ops):
+    n = 10007
+    p0, g = rnd(n, seed=1), rnd(n, seed=2, scale=0.1)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-4, weight_decay=0.01, eps=1e-8)
+    for step in range(1, 4):
+        lr, b1 = O.onecycle(step - 1, 100)
+        opt.param_groups[0]["lr"], opt.param_groups[0]["betas"] = lr, (b1, 0.999)
+        ref.grad = g.clone()
+        opt.step()
+        bc1, bc2 = 1 - b1 ** step, 1 - 0.999 ** step
+        hyper = torch.tensor([1 - lr * 0.01, 1 - b1, 0.999, 1 - 0.999, lr / bc1, math.sqrt(bc2), 1e-8, 1.0], device="cuda")
+        ops.adamw_step(p, g, m, v, None, n, hyper)
+        close(p, ref.data, rtol=1e-6, atol=1e-7, msg=f"adamw step {step}")
+
+
+def test_gemm_dropout_matches_dropout_apply(ops):
+    M, N, K, p = 300, 256, 64, 0.4
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 99)
+    y0, y1, y2 = (torch.empty(M, N, device="cuda") for _ in range(3))
+    ops.gemm(x, w, y0, M, N, K, lda=K, ldb=K, ldc=N)
+    ops.gemm(x, w, y1, M, N, K, lda=K, ldb=K, ldc=N, drop=ops.dropout(state, 5, p))
+    ops.dropout_apply(y0, y2, M, N, ops.dropout(state, 5, p))
+    assert torch.equal(y1, y2), "GEMM-epilogue dropout and dropout_apply must share the mask"
+    kept = (y1 != 0).float().mean().item()
+    assert abs(kept - (1 - p)) < 0.01
+    nz = y1 != 0
+    close(y1[nz], y0[nz] / (1 - p), msg="scaled by 1/(1-p)")
+    ops.dropout_apply(y0, y2, M, N, ops.dropout(state, 6, p))
+    assert not torch.equal(y1, y2), "different site -> different mask"
