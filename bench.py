@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Headline benchmark: masked-pretraining samples/s on synthetic (neurons x timebins x modalities)
+batches through the drop-in path (MultiModalTrainer step -> MultiModal.forward -> HIP engine ->
+backward -> fused AdamW), BASELINE.json configs[1]: 1 session, spike + behaviour, d_model=256,
+5+5 layers, T=100 bins per modality.
+
+    python bench.py --gpus N --steps K --warmup W [--batch B] [--dtype fp32|bf16]
+
+N>1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL); every rank
+processes its own batch of B samples (weak scaling) and gradients are mean-all-reduced in buckets
+overlapped with backward.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "multi_modal_foundation_model_amd", "src"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0}     # MI355X dense MFMA peaks (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MMFM_BENCH_BATCH", "256")), help="samples per GPU per step")
+    ap.add_argument("--dtype", default=os.environ.get("MMFM_DTYPE", "fp32"), choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    return ap.parse_args()
+
+
+def flops_per_sample_fwd(cfg, channels, T):
+    """MACs of one forward per sample (x2 = FLOP; a train step is 3x forward)."""
+    H, I = cfg.hidden, cfg.inter
+    M = len(channels)
+    L = M * T
+    mac = 0
+    for n in channels:
+        mac += 2 * T * (n * 2 * n + 2 * n * H) + T * H * n
+    mac += cfg.n_enc * (L * (4 * H * H + 2 * H * I) + 2 * L * L * H)
+    mac += L * H * H
+    mac += cfg.n_dec * (L * (8 * H * H + 2 * H * I) + 4 * L * L * H)
+    return 2 * mac
+
+
+def kernel_profile(engine, plan, reps=3):
+    """Per-launch timing of every entry of the step plan with HIP events on the launch stream."""
+    import ctypes
+    from multi_modal_foundation_model_amd import _lib as L
+    st = torch.cuda.current_stream().cuda_stream
+    entries = list(plan["fwd"]) + [e for _, seg in plan["bwd"] for e in seg]
+    rows = []
+    for fn, args, keep in entries:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn(*args, st)
+        torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(reps):
+            fn(*args, st)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / reps
+        name, flops = fn.__name__, 0.0
+        if name == "mmfm_gemm":
+            d = keep[0]
+            flops = 2.0 * d.M * d.N * d.K
+            name = f"mmfm_gemm[{'T' if not d.a_kcontig else 'N'}{'T' if d.b_kcontig else 'N'}]"
+        elif name in ("mmfm_attn_fwd", "mmfm_attn_bwd"):
+            d = keep[0]
+            flops = (4.0 if name.endswith("fwd") else 10.0) * d.B * d.heads * d.Lq * d.Lk * d.dh
+        rows.append((name, ms, flops))
+    agg = {}
+    for name, ms, fl in rows:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += fl
+    return agg
+
+
+def cpu_baseline(steps, B=16):
+    """The CPU oracle (oracle/mm_oracle.py, pinned against the reference's fixtures) on the host cores:
+    the same synthetic step (forward + autograd backward + AdamW), dropout as configured, B=16
+    (the reference's batch size).  A reported baseline, not the target."""
+    from oracle import mm_oracle as O
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, int(os.environ.get("MMFM_CPU_THREADS", "16"))))     # the 1-GPU box's CPU share is 16
+    torch.set_num_threads(cores)
+    cfg = O.OracleCfg()
+    sd = O.init_state_dict(cfg, seed=42)
+    mk = dict(force_active=True, mode="temporal", ratio=0.3, zero_ratio=1.0, random_ratio=1.0, expand_prob=0.0, max_timespan=1,
+              channels=None, timesteps=None, mask_regions=["all"], target_regions=["all"], n_mask_regions=1, causal_zero=True)
+    tr = O.OracleTrainer(sd, cfg, mk, total_steps=1000)
+    objs = O.objective_schedule(steps + 1)
+    batches = [O.synth_batch(B, 100, 668, 2, seed=s) for s in range(steps + 1)]
+    tr.step(batches[0], objs[0])                       # warm-up
+    t0 = time.perf_counter()
+    for s in range(1, steps + 1):
+        tr.step(batches[s], objs[s])
+    dt = time.perf_counter() - t0
+    return dict(value=round(B * steps / dt, 3), unit="samples/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"{steps} train steps (fwd+bwd+AdamW) at B={B}, T=100, 668+2 channels, fp32 torch-CPU oracle, dropout as configured, "
+                       f"{dt:.1f} s of CPU work")
+
+
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    try:
+        torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
+    except AttributeError:
+        pass
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from helpers import build_model, load_config
+    from torch.optim.lr_scheduler import OneCycleLR
+    from multi_modal_foundation_model_amd.ddp import DataParallelModel
+    from multi_modal_foundation_model_amd.optim import make_optimizer
+    from multi_modal_foundation_model_amd.synthetic import synth_batch
+    from trainer.make import make_multimodal_trainer
+
+    cfg = load_config()
+    B, T, n_ap, n_beh = a.batch, 100, 668, 2
+    model = build_model(cfg.model, n_ap, n_beh, seed=cfg.seed)          # same init on every rank (set_seed(42) upstream)
+    model.compute_dtype = a.dtype
+    model.engine_seed = 1234 + rank
+    model.masker.token_mask_only = True     # the [B,T,N] corruption draws are dead work in the embd path
+    model = model.to(dev)
+    if world > 1:
+        model = DataParallelModel(model)
+    total = max(1000, a.steps + a.warmup + 1)
+    opt = make_optimizer(model, lr=cfg.optimizer.lr, weight_decay=cfg.optimizer.wd, eps=cfg.optimizer.eps)
+    sch = OneCycleLR(optimizer=opt, total_steps=total, max_lr=cfg.optimizer.lr, pct_start=cfg.optimizer.warmup_pct,
+                     div_factor=cfg.optimizer.div_factor)
+
+    class Acc:
+        device = dev
+    tr = make_multimodal_trainer(model=model, train_dataloader=[], eval_dataloader=[], optimizer=opt, log_dir="/tmp", accelerator=Acc(),
+                                 lr_scheduler=sch, avail_mod=["ap", "behavior"], config=cfg,
+                                 modal_filter=dict(input=["ap", "behavior"], output=["ap", "behavior"]), mixed_training=True,
+                                 num_neurons=[n_ap])
+    # synthetic batches, resident in HBM before the timed region (pool of 4 per rank, cycled)
+    pool = []
+    for i in range(4):
+        b = synth_batch(B, T, n_ap, n_beh, seed=1000 * rank + i)
+        pool.append({k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()})
+    random.seed(42)                                   # same objective on every rank, different data/masks
+    torch.manual_seed(4242 + rank)
+    model.train()
+
+    def step(i):
+        tr._sample_modes()
+        out = tr._forward_model_outputs(dict(pool[i % len(pool)]), masking_mode=tr.masking_mode, training_mode=tr.training_mode)
+        out.loss.backward()
+        opt.step()
+        sch.step()
+        opt.zero_grad()
+        return out.loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        log(f"model built ({a.dtype}, B={B}/GPU, world={world}); warm-up {a.warmup} steps")
+    for i in range(a.warmup):
+        loss = step(i)
+    barrier()
+    if rank == 0:
+        log(f"timing {a.steps} steps")
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = tmax.item()
+    last_loss = loss.item()
+
+    inner = getattr(model, "module", model)
+    eng = inner._engine
+    res = None
+    if rank == 0:
+        ms = dt / a.steps * 1e3
+        value = world * B * a.steps / dt
+        fl_step = 3 * flops_per_sample_fwd(eng.cfg, [n_ap, n_beh], T) * B
+        res = dict(metric="pretrain samples/sec (T=100 bins/modality, d_model=256, 5+5 layers, spike+behaviour masked pretraining step)",
+                   value=round(value, 2), unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
+                   higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
+                   config=dict(workload="BASELINE.json configs[1]: 1 session, ap(668 neurons)+behaviour(2), d_model=256, heads=8, mlp=512, "
+                                        "5 enc + 5 dec layers, T=100 (L=200 tokens), dropout 0.4/0.2, AdamW+OneCycleLR, mixed objectives",
+                               per_gpu_batch=B, global_batch=B * world, seq_len=200, parallelism=f"dp{world}"),
+                   samples_per_sec_per_gpu=round(value / world, 2), final_loss=round(last_loss, 5),
+                   model_tflops_per_gpu=round(fl_step / (dt / a.steps) / 1e12, 2),
+                   frac_of_mfma_peak_whole_step=round(fl_step / (dt / a.steps) / 1e12 / PEAK_TFLOPS[a.dtype], 4))
+        log(f"{ms:.2f} ms/step, {value:.1f} samples/s")
+        if not a.no_kernel_profile:
+            log("per-kernel HIP-event profile")
+            agg = kernel_profile(eng, eng._last)
+            tot = sum(v[1] for v in agg.values())
+            top = sorted(agg.items(), key=lambda kv: -kv[1][1])
+            res["kernel_breakdown_ms"] = {k: round(v[1], 3) for k, v in top[:8]}
+            res["kernel_time_sum_ms"] = round(tot, 3)
+            mf = [(k, v) for k, v in top if v[2] > 0]
+            k, v = mf[0]
+            achieved = v[2] / (v[1] * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):
+                with open(tpath) as f:
+                    traffic = json.load(f).get(k)
+            res["roofline"] = dict(bound="mfma", kernel=k, launches_per_step=v[0], achieved=round(achieved, 2),
+                                   peak=PEAK_TFLOPS[a.dtype], unit="TFLOP/s", frac=round(achieved / PEAK_TFLOPS[a.dtype], 4),
+                                   traffic=traffic, avg_launch_ms=round(v[1] / v[0], 4),
+                                   algorithmic_flops_per_launch=v[2] / v[0])
+        if world == 1 and not a.no_cpu_baseline:
+            log("CPU baseline (oracle on host cores)")
+            res["cpu_baseline"] = cpu_baseline(a.cpu_steps)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -155,10 +155,12 @@ int mmfm_stitch_fwd(int dtype, const void* tok, const float* mod_emb_row, const 
                     int B, int T, int L, int m, int H, int max_F, mmfm_stream stream);
 /* autograd of the above for one modality: d_tok[b*T+t] = keep0 * dropout'(dx[b, m*T+t]);
  * d_mod_row (+)= sum_{b,t} (dx + dextra);  d_pos[ts[b][t]] (+)= dx + dextra  (dextra may be NULL:
- * it is d_context -> encoder_emb, mm.py:292).  Deterministic two-stage scatter (no atomics). */
+ * it is d_context -> encoder_emb, mm.py:292).  acc_mod / acc_pos select += for each output (the
+ * modality embedding is shared by the encoder and decoder tokenisers, mm.py:84-87, the position
+ * tables are not).  Deterministic two-stage scatter (no atomics). */
 int64_t mmfm_stitch_bwd_workspace(int B, int T, int H, int max_F);
 int mmfm_stitch_bwd(int dtype, const void* dx, const void* dextra, const int64_t* ts, const uint8_t* keep0,
-                    mmfm_dropout drop, void* d_tok, float* d_mod_row, float* d_pos, int accumulate,
+                    mmfm_dropout drop, void* d_tok, float* d_mod_row, float* d_pos, int acc_mod, int acc_pos,
                     int B, int T, int L, int m, int H, int max_F,
                     void* workspace, int64_t workspace_bytes, mmfm_stream stream);
 

@@ -9,6 +9,11 @@ import ctypes as C
 import os
 import re
 
+# torch ships its own ROCm runtime (libamdhip64 under torch/lib).  It MUST be loaded before
+# libmmfm_hip.so so that both resolve to the same HIP runtime instance: device pointers and streams
+# handed over by torch are only meaningful inside the runtime that created them.
+import torch  # noqa: F401  (load order matters)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmmfm_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmfm.h")
@@ -66,7 +71,7 @@ _PROTOS = {
     "mmfm_mask_prep": (C.c_int, [_i, _i, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmfm_stitch_fwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "mmfm_stitch_bwd_workspace": (C.c_int64, [_i, _i, _i, _i]),
-    "mmfm_stitch_bwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, Dropout, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "mmfm_stitch_bwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, Dropout, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
     "mmfm_masked_loss_workspace": (C.c_int64, [_i64, _i]),
     "mmfm_masked_loss_fwd": (C.c_int, [_i, _i, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _i64, _vp]),
     "mmfm_loss_finalize": (C.c_int, [_vp, _vp, _i, _vp, _vp, _vp]),

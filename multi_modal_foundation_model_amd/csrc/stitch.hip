@@ -159,7 +159,7 @@ extern "C" int64_t mmfm_stitch_bwd_workspace(int B, int T, int H, int max_F) {
 }
 
 extern "C" int mmfm_stitch_bwd(int dtype, const void* dx, const void* dextra, const int64_t* ts, const uint8_t* keep0,
-                               mmfm_dropout drop, void* d_tok, float* d_mod_row, float* d_pos, int accumulate, int B, int T,
+                               mmfm_dropout drop, void* d_tok, float* d_mod_row, float* d_pos, int acc_mod, int acc_pos, int B, int T,
                                int L, int m, int H, int max_F, void* workspace, int64_t workspace_bytes, mmfm_stream stream) {
     MMFM_REQUIRE(dx && ts && keep0 && d_mod_row && d_pos, "mmfm_stitch_bwd: null pointer");
     MMFM_REQUIRE(B > 0 && T > 0 && H > 0 && max_F > 0 && m >= 0 && (m + 1) * T <= L, "mmfm_stitch_bwd: bad shape");
@@ -181,6 +181,6 @@ extern "C" int mmfm_stitch_bwd(int dtype, const void* dx, const void* dextra, co
         return mmfm_set_error(-1, "mmfm_stitch_bwd: bad dtype %d", dtype);
     MMFM_LAUNCH_CHECK("mmfm_stitch_bwd");
     const int64_t stride = (int64_t)(max_F + 1) * H;
-    if (int rc = mmfm_reduce_slabs(d_pos, (const float*)workspace, (int64_t)max_F * H, nch, stride, accumulate, stream)) return rc;
-    return mmfm_reduce_slabs(d_mod_row, (const float*)workspace + (size_t)max_F * H, H, nch, stride, accumulate, stream);
+    if (int rc = mmfm_reduce_slabs(d_pos, (const float*)workspace, (int64_t)max_F * H, nch, stride, acc_pos, stream)) return rc;
+    return mmfm_reduce_slabs(d_mod_row, (const float*)workspace + (size_t)max_F * H, H, nch, stride, acc_mod, stream);
 }

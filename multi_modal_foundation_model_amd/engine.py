@@ -197,7 +197,8 @@ class Engine:
         self._token = 0
         self._fwd_token = -1
         self._sites: Dict[str, int] = {}
-        self.grad_ready_hooks = []       # DDP: callables(segment_name, start, end) fired during backward
+        self.grad_ready_hooks = []       # DDP: callables(segment_name) fired as backward completes a segment of G
+        self.backward_done_hooks = []    # DDP: wait for the collectives (stream-side) before anyone reads G
         self.b["loss"] = torch.zeros(1, device=self.device)
         self.b["inv_n"] = torch.zeros(1, device=self.device)
         self.b["gout"] = torch.ones(1, device=self.device)
@@ -433,32 +434,31 @@ class Engine:
         ln_b(cur, dydec, dec_last, "decoder_norm", "decnorm", None, dY, ds_L=Lq, ds_T=T)
         close_segment("head")
 
-        def mlp_back(plan, p, tag, X_in):
-            """X_in = the stream value that fed ln2 (= this block's residual input)."""
-            dYd = dY
-            if dp > 0:
-                K.dropout_apply(dY, t1, R, H, self._drop(tag + "/mlpdrop", dp), plan=plan)
-                dYd = t1
-            dlin(plan, dYd, self.b[tag + "/g"], p + ".mlp.down_proj", R, H, I, dX=du, act=L.ACT_GELU_GRAD, gradmul_pre=self.b[tag + "/u"])
+        def mlp_back(plan, dS, p, tag, X_in):
+            """dS: running gradient of the residual stream (in place).  X_in = the stream value that fed ln2."""
+            dSd = dS
+            if dp > 0:                                                       # mm_utils.py:52 dropout(down_proj(.))
+                K.dropout_apply(dS, t1, R, H, self._drop(tag + "/mlpdrop", dp), plan=plan)
+                dSd = t1
+            dlin(plan, dSd, self.b[tag + "/g"], p + ".mlp.down_proj", R, H, I, dX=du, act=L.ACT_GELU_GRAD, gradmul_pre=self.b[tag + "/u"])
             dlin(plan, du, self.b[tag + "/h2"], p + ".mlp.up_proj", R, I, H, dX=dh_)
-            ln_b(plan, dh_, X_in, p + ".ln2", tag + "/ln2", dY, dY)
+            ln_b(plan, dh_, X_in, p + ".ln2", tag + "/ln2", dS, dS)
 
-        def self_back(plan, p, tag, X_in, flags):
-            dlin(plan, dY, self.b[tag + "/a"], p + ".attn.out_proj", R, H, H, dX=t2)
+        def self_back(plan, dS, p, tag, X_in, flags):
+            dlin(plan, dS, self.b[tag + "/a"], p + ".attn.out_proj", R, H, H, dX=t2)
             qkv = self.b[tag + "/qkv"]
             K.attn_bwd(attn_desc(tag + "/sa", qkv, 3 * H, qkv, 3 * H, H, 2 * H, self.b[tag + "/a"], flags, d_o=t2, dq=dqkv, dkv=dqkv,
                                  lddq=3 * H, lddkv=3 * H, dkoff=H, dvoff=2 * H), plan=plan)
             dlin(plan, dqkv, self.b[tag + "/h1"], p + ".attn.qkv", R, 3 * H, H, dX=dh_)
-            ln_b(plan, dh_, X_in, p + ".ln1", tag + "/ln1", dY, dY)
+            ln_b(plan, dh_, X_in, p + ".ln1", tag + "/ln1", dS, dS)
 
+        dqc, dkvc = buf("d/qc", (R, H)), buf("d/kvc", (R, 2 * H))
         first_ctx = True
         for i in reversed(range(c.n_dec)):
             p, tag = f"decoder.{i}", f"dec{i}"
-            mlp_back(cur, p, tag, self.b[tag + "/yb"])
-            # cross attention
+            mlp_back(cur, dY, p, tag, self.b[tag + "/yb"])
+            # cross attention (decoder_embeddings.py:143): query side -> stream, context side -> dctx
             dlin(cur, dY, self.b[tag + "/a2"], p + ".cross_attn.out_proj", R, H, H, dX=t2)
-            dqc, dkvc = dqkv[:, :H], None
-            dqc = buf("d/qc", (R, H)); dkvc = buf("d/kvc", (R, 2 * H))
             K.attn_bwd(attn_desc(tag + "/xa", self.b[tag + "/qc"], H, self.b[tag + "/kvc"], 2 * H, 0, H, self.b[tag + "/a2"], enc_flags,
                                  d_o=t2, dq=dqc, dkv=dkvc, lddq=H, lddkv=2 * H, dkoff=0, dvoff=H), plan=cur)
             dlin(cur, dqc, self.b[tag + "/hq"], p + ".cross_attn.query", R, H, H, dX=dh_)
@@ -466,52 +466,27 @@ class Engine:
             dlin(cur, dkvc, self.b[tag + "/hc"], p + ".cross_attn.kv", R, 2 * H, H, dX=dh_)
             ln_b(cur, dh_, context, p + ".context_norm", tag + "/cn", None if first_ctx else dctx, dctx)
             first_ctx = False
-            self_back(cur, p, tag, stream_in[tag], dec_flags)
+            self_back(cur, dY, p, tag, stream_in[tag], dec_flags)
             close_segment(p)
-        # dY = d(dec_tokens + dec_emb); dctx = d(context) = d(ctx_proj out) = d(encoder_emb) contribution
-        emb_tail = []
-        for m, (mod, n) in enumerate(c.mods):
-            pD = f"decoder_embeddings.{mod}.embedder"
-            K.stitch_bwd(dY, None, ts, keep0, self._drop(f"decoder/embdrop/{m}", dpe), buf(f"d/tok/decoder/{m}", (BT, H)),
-                         self.Gv(f"encoder_embeddings.{mod}.embedder.mod_emb.weight")[m], self.Gv(pD + ".pos_embed.weight"), False,
-                         B, T, Lq, m, H, c.max_F, ws_st, plan=emb_tail)
         if c.n_dec == 0:
             raise NotImplementedError("n_dec == 0")
+        # now dY = d(dec_tokens + dec_emb) and dctx = d(context); context = ctx_proj(enc_out) + encoder_emb (mm.py:292)
         dX = buf("d/xstream", (R, H))
         dlin(cur, dctx, enc_out, "decoder_proj_context", R, H, H, dX=dh_)
         ln_b(cur, dh_, enc_last, "encoder_norm", "encnorm", None, dX)
         close_segment("bridge")
-        dY_save = dY
-        dY = dX      # the helpers below close over `dY`: rebind for the encoder stream
-
-        def mlp_back_e(plan, p, tag, X_in):
-            dYd = dX
-            if dp > 0:
-                K.dropout_apply(dX, t1, R, H, self._drop(tag + "/mlpdrop", dp), plan=plan)
-                dYd = t1
-            dlin(plan, dYd, self.b[tag + "/g"], p + ".mlp.down_proj", R, H, I, dX=du, act=L.ACT_GELU_GRAD, gradmul_pre=self.b[tag + "/u"])
-            dlin(plan, du, self.b[tag + "/h2"], p + ".mlp.up_proj", R, I, H, dX=dh_)
-            ln_b(plan, dh_, X_in, p + ".ln2", tag + "/ln2", dX, dX)
-
-        def self_back_e(plan, p, tag, X_in, flags):
-            dlin(plan, dX, self.b[tag + "/a"], p + ".attn.out_proj", R, H, H, dX=t2)
-            qkv = self.b[tag + "/qkv"]
-            K.attn_bwd(attn_desc(tag + "/sa", qkv, 3 * H, qkv, 3 * H, H, 2 * H, self.b[tag + "/a"], flags, d_o=t2, dq=dqkv, dkv=dqkv,
-                                 lddq=3 * H, lddkv=3 * H, dkoff=H, dvoff=2 * H), plan=plan)
-            dlin(plan, dqkv, self.b[tag + "/h1"], p + ".attn.qkv", R, 3 * H, H, dX=dh_)
-            ln_b(plan, dh_, X_in, p + ".ln1", tag + "/ln1", dX, dX)
-
         for i in reversed(range(c.n_enc)):
             p, tag = f"encoder.{i}", f"enc{i}"
-            mlp_back_e(cur, p, tag, self.b[tag + "/xa"])
-            self_back_e(cur, p, tag, stream_in[tag], enc_flags)
+            mlp_back(cur, dX, p, tag, self.b[tag + "/xa"])
+            self_back(cur, dX, p, tag, stream_in[tag], enc_flags)
             close_segment(p)
-        cur.extend(emb_tail)
-        for m, (mod, n) in enumerate(c.mods):
-            pE = f"encoder_embeddings.{mod}.embedder"
-            K.stitch_bwd(dX, dctx, ts, keep0, self._drop(f"encoder/embdrop/{m}", dpe), buf(f"d/tok/encoder/{m}", (BT, H)),
-                         self.Gv(pE + ".mod_emb.weight")[m], self.Gv(pE + ".pos_embed.weight"), True,
-                         B, T, Lq, m, H, c.max_F, ws_st, plan=cur)
+        # tokenisers: decoder side first (it overwrites the shared mod_emb gradient row, the encoder side adds)
+        for side, dS, dextra, acc_mod in (("decoder", dY, None, False), ("encoder", dX, dctx, True)):
+            for m, (mod, n) in enumerate(c.mods):
+                pS = f"{side}_embeddings.{mod}.embedder"
+                K.stitch_bwd(dS, dextra, ts, keep0, self._drop(f"{side}/embdrop/{m}", dpe), buf(f"d/tok/{side}/{m}", (BT, H)),
+                             self.Gv(f"encoder_embeddings.{mod}.embedder.mod_emb.weight")[m], self.Gv(pS + ".pos_embed.weight"),
+                             acc_mod, False, B, T, Lq, m, H, c.max_F, ws_st, plan=cur)
         for side in ("decoder", "encoder"):
             for m, (mod, n) in enumerate(c.mods):
                 p = f"{side}_embeddings.{mod}.embedder"
@@ -577,6 +552,8 @@ class Engine:
             for hook in self.grad_ready_hooks:
                 for name, _ in self._last["bwd"]:
                     hook(name)
+        for hook in self.backward_done_hooks:
+            hook()
         for name, p in self.params.items():
             if p.grad is None or p.grad.data_ptr() != self.Gv(name).data_ptr():
                 p.grad = self.Gv(name)

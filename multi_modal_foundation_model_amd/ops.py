@@ -114,9 +114,9 @@ def stitch_fwd(tok, mod_row, pos, ts, keep0, x, emb, B, T, Lseq, m, H, max_F, pl
     _emit(plan, L.lib().mmfm_stitch_fwd, (dt(tok), P(tok), P(mod_row), P(pos), P(ts), P(keep0), P(x), P(emb), B, T, Lseq, m, H, max_F))
 
 
-def stitch_bwd(dx, dextra, ts, keep0, drop, d_tok, d_mod_row, d_pos, accumulate, B, T, Lseq, m, H, max_F, ws, plan=None):
+def stitch_bwd(dx, dextra, ts, keep0, drop, d_tok, d_mod_row, d_pos, acc_mod, acc_pos, B, T, Lseq, m, H, max_F, ws, plan=None):
     _emit(plan, L.lib().mmfm_stitch_bwd, (dt(dx), P(dx), P(dextra), P(ts), P(keep0), drop if drop is not None else L.NO_DROP,
-                                          P(d_tok), P(d_mod_row), P(d_pos), int(accumulate), B, T, Lseq, m, H, max_F, P(ws),
+                                          P(d_tok), P(d_mod_row), P(d_pos), int(acc_mod), int(acc_pos), B, T, Lseq, m, H, max_F, P(ws),
                                           ws.numel() * ws.element_size()))
 
 

@@ -1,0 +1,48 @@
+"""`__graft_entry__.smoke()`: one tiny train step of the hot path on cuda:0, checked against the CPU oracle."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "multi_modal_foundation_model_amd", "src"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def smoke():
+    from helpers import build_model, make_optimizer, tiny_config
+    from oracle import mm_oracle as O
+    assert torch.cuda.is_available(), "smoke() needs the MI355X"
+    mc = tiny_config(n_enc=2, n_dec=2)
+    model = build_model(mc, 12, 2, seed=7)
+    cfg = O.OracleCfg.from_model_config(mc, {"ap": 12, "behavior": 2})
+    sd = O.share_mod_emb({k: v.detach().clone() for k, v in model.state_dict().items()}, cfg)
+    keys = O.trainable_keys(sd, cfg)
+    for k in keys:
+        sd[k].requires_grad_(True)
+    batch = O.synth_batch(4, 8, 12, 2, seed=1, pad=[0, 2, 0, 0])
+    ref = O.forward(sd, O.make_mod_dict(batch, "encoding"), cfg, training=True)
+    ref_g = torch.autograd.grad(ref["loss"], [sd[k] for k in keys])
+    model.cuda().train()
+    md = O.make_mod_dict(batch, "encoding")
+    for d in md.values():
+        for k, v in list(d.items()):
+            if isinstance(v, torch.Tensor):
+                d[k] = v.cuda()
+    opt, sch = make_optimizer(model, 10)
+    out = model(md)
+    out.loss.backward()
+    err = abs(out.loss.item() - ref["loss"].item())
+    assert err < 1e-5 * abs(ref["loss"].item()) + 1e-6, f"loss mismatch {out.loss.item()} vs {ref['loss'].item()}"
+    named = dict(model.named_parameters())
+    worst, worst_key = 0.0, ""
+    gmax = max(g.abs().max().item() for g in ref_g)
+    for k, g in zip(keys, ref_g):      # error relative to the tensor's own scale, floored at 1e-4 of the largest gradient
+        d = (named[k].grad.cpu() - g).abs().max().item() / max(g.abs().max().item(), 1e-4 * gmax)
+        if d > worst:
+            worst, worst_key = d, k
+    assert worst < 2e-3, f"gradient mismatch {worst} at {worst_key}"
+    opt.step(); sch.step(); opt.zero_grad()
+    torch.cuda.synchronize()
+    print(f"smoke ok: loss {out.loss.item():.6f} (oracle {ref['loss'].item():.6f}), worst relative grad error {worst:.2e}")

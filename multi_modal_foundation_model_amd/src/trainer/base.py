@@ -1,0 +1,206 @@
+"""`MultiModalTrainer` — the reference's epoch loop (trainer/base.py:10-308) around the HIP engine.
+
+Same constructor kwargs (log_dir, accelerator, lr_scheduler, config, num_neurons, avail_mod,
+modal_filter, mixed_training), same methods and return values.  Differences, all on the host side:
+  * the per-step `loss.item()` sync (trainer/base.py:199) is deferred to the end of the epoch: losses
+    stay on the device and are summed in float64 in step order, which gives the same `train_loss`;
+  * wandb / matplotlib are optional (absent in this image): logging falls back to print / PNG files.
+"""
+import os
+import random
+
+import numpy as np
+import torch
+
+from utils.utils import metrics_list, move_batch_to_device, plot_gt_pred, plot_neurons_r2
+
+try:                       # optional, like the reference's `config.wandb.use`
+    import wandb
+except Exception:          # pragma: no cover
+    wandb = None
+
+OBJECTIVES = ['encoding', 'decoding', 'token_masking']
+
+
+class MultiModalTrainer():
+    def __init__(self, model, train_dataloader, eval_dataloader, optimizer, **kwargs):
+        self.model = model
+        self.train_dataloader = train_dataloader
+        self.eval_dataloader = eval_dataloader
+        self.optimizer = optimizer
+
+        self.log_dir = kwargs.get("log_dir", None)
+        self.accelerator = kwargs.get("accelerator", None)
+        self.lr_scheduler = kwargs.get("lr_scheduler", None)
+        self.config = kwargs.get("config", None)
+        self.num_neurons = kwargs.get("num_neurons", None)
+
+        self.model_class = self.config.model.model_class
+        self.metric = 'r2'
+        self.session_active_neurons = []
+        self.avail_mod = kwargs.get("avail_mod", None)
+        self.modal_filter = kwargs.get("modal_filter", None)
+        self.mod_to_indx = {r: i for i, r in enumerate(self.avail_mod)}
+
+        if self.config.training.mask_type == "input":
+            self.masking_schemes = self.config.training.mask_mode
+        else:
+            self.masking_mode = None
+        self.mixed_training = kwargs.get("mixed_training", False)
+        if self.mixed_training:
+            self.training_schemes = list(OBJECTIVES)
+        else:
+            self.training_mode = None
+        self.use_wandb = bool(self.config.wandb.use) and wandb is not None
+
+    # ------------------------------------------------------------------ batch -> mod_dict (trainer/base.py:51-103)
+    def _forward_model_outputs(self, batch, masking_mode, training_mode):
+        single_modal = len(self.modal_filter['output']) == 1
+        dev = self.accelerator.device
+        batch = move_batch_to_device(batch, dev)
+        spikes, behav = batch['spikes_data'], batch['target']
+
+        def const_mask(like, value):
+            return torch.full(like.shape, value, dtype=torch.int64, device=like.device)
+
+        mod_dict = {}
+        for mod, idx in self.mod_to_indx.items():
+            d = {
+                'inputs_modality': torch.tensor(idx, device=dev), 'targets_modality': torch.tensor(idx, device=dev),
+                'inputs_attn_mask': batch['time_attn_mask'], 'inputs_timestamp': batch['spikes_timestamps'],
+                'targets_timestamp': batch['spikes_timestamps'], 'eid': batch['eid'][0],
+                'num_neuron': spikes.shape[2], 'masking_mode': masking_mode,
+            }
+            if mod == 'ap':
+                d['inputs'], d['targets'] = spikes.clone(), spikes.clone()
+                d['inputs_regions'] = np.asarray(batch['neuron_regions']).T
+            elif mod == 'behavior':
+                d['inputs'], d['targets'] = behav.clone(), behav.clone()
+            else:
+                raise Exception(f"Modality not implemented yet.")
+            d['eval_mask'] = const_mask(spikes, 1 if (single_modal and mod in self.modal_filter['output']) else 0)
+            mod_dict[mod] = d
+
+        if not single_modal:
+            if training_mode == 'encoding':        # predict spikes from behaviour: every ap bin is a target
+                for mod in mod_dict:
+                    mod_dict[mod]['eval_mask'] = const_mask(spikes, 1 if mod == 'ap' else 0)
+            elif training_mode == 'decoding':      # predict behaviour from spikes
+                for mod in mod_dict:
+                    mod_dict[mod]['eval_mask'] = const_mask(behav, 1 if mod == 'behavior' else 0)
+            elif training_mode == 'token_masking':  # the model's masker draws the targets
+                for mod in mod_dict:
+                    mod_dict[mod]['eval_mask'] = None
+            else:
+                raise Exception(f"Training objective not implemented yet.")
+        return self.model(mod_dict)
+
+    # ------------------------------------------------------------------ epochs
+    def train(self):
+        best_eval_loss = torch.tensor(float('inf'))
+        best_metric = -torch.tensor(float('inf'))
+        epoch = -1
+        for epoch in range(self.config.training.num_epochs):
+            train_res = self.train_epoch(epoch)
+            eval_res = self.eval_epoch()
+            print(f"epoch: {epoch} train loss: {train_res['train_loss']}")
+            key = f'eval_trial_avg_{self.metric}'
+            if eval_res:
+                if eval_res[key] > best_metric:
+                    best_eval_loss, best_metric = eval_res['eval_loss'], eval_res[key]
+                    print(f"epoch: {epoch} best eval loss: {best_eval_loss} trial avg {self.metric}: {best_metric}")
+                    self.save_model(name="best", epoch=epoch)
+                    self._log_figures(eval_res, epoch, prefix="best_")
+                print(f"epoch: {epoch} eval loss: {eval_res['eval_loss']} trial avg {self.metric}: {eval_res[key]}")
+            if epoch % self.config.training.save_plot_every_n_epochs == 0:
+                self._log_figures(eval_res, epoch, prefix="")
+            if self.use_wandb:
+                wandb.log({"train_loss": train_res['train_loss'], "eval_loss": eval_res['eval_loss'], key: eval_res[key]})
+        self.save_model(name="last", epoch=epoch)
+        if self.use_wandb:
+            wandb.log({"best_eval_loss": best_eval_loss, f"best_eval_trial_avg_{self.metric}": best_metric})
+
+    def _log_figures(self, eval_res, epoch, prefix):
+        for mod in self.modal_filter['output']:
+            try:
+                figs = self.plot_epoch(gt=eval_res['eval_gt'][0][mod], preds=eval_res['eval_preds'][0][mod], epoch=epoch,
+                                       active_neurons=self.session_active_neurons[0][:5], modality=mod)
+            except ImportError:          # matplotlib not installed: plotting is optional
+                return
+            if self.use_wandb:
+                wandb.log({f"{prefix}gt_pred_fig_{mod}": wandb.Image(figs['plot_gt_pred']),
+                           f"{prefix}r2_fig_{mod}": wandb.Image(figs['plot_r2'])})
+            else:
+                figs['plot_gt_pred'].savefig(os.path.join(self.log_dir, f"{prefix}gt_pred_fig_{mod}_{epoch}.png"))
+                figs['plot_r2'].savefig(os.path.join(self.log_dir, f"{prefix}r2_fig_{mod}_{epoch}.png"))
+
+    def _sample_modes(self):
+        if self.config.training.mask_type == "input":
+            self.masking_mode = random.sample(self.masking_schemes, 1)[0]
+        if self.mixed_training:
+            self.training_mode = random.sample(self.training_schemes, 1)[0]
+
+    def train_epoch(self, epoch):
+        self.model.train()
+        losses = []
+        for batch in self.train_dataloader:
+            self._sample_modes()
+            outputs = self._forward_model_outputs(batch, masking_mode=self.masking_mode, training_mode=self.training_mode)
+            loss = outputs.loss
+            loss.backward()
+            self.optimizer.step()
+            self.lr_scheduler.step()
+            self.optimizer.zero_grad()
+            losses.append(loss.detach())
+        # one host sync per epoch instead of one per step; float64 sum in step order == sum of .item()s
+        train_loss = float(sum(x.item() for x in torch.stack(losses).double().cpu())) if losses else 0.
+        return {"train_loss": train_loss}
+
+    def eval_epoch(self):
+        self.model.eval()
+        eval_loss = 0.
+        results = {n: {mod: {"gt": [], "preds": []} for mod in self.modal_filter['output']} for n in self.num_neurons}
+        if not self.eval_dataloader:
+            return None
+        with torch.no_grad():
+            for batch in self.eval_dataloader:
+                self._sample_modes()
+                outputs = self._forward_model_outputs(batch, masking_mode=self.masking_mode, training_mode=self.training_mode)
+                eval_loss += outputs.loss.item()
+                n = batch['spikes_data'].shape[2]
+                for mod in self.modal_filter['output']:
+                    sl = slice(None, n) if mod == 'ap' else slice(None)
+                    results[n][mod]["gt"].append(outputs.mod_targets[mod].clone()[:, :, sl])
+                    results[n][mod]["preds"].append(outputs.mod_preds[mod].clone()[:, :, sl])
+        gt, preds, scores = {}, {}, []
+        for idx, n in enumerate(self.num_neurons):
+            gt[idx], preds[idx] = {}, {}
+            for mod in self.modal_filter['output']:
+                g = torch.cat(results[n][mod]["gt"], dim=0)
+                p = torch.cat(results[n][mod]["preds"], dim=0)
+                gt[idx][mod] = g
+                preds[idx][mod] = torch.exp(p) if mod == 'ap' else p        # rates from log-rates
+            for mod in self.modal_filter['output']:
+                active = np.argsort(gt[idx][mod].cpu().numpy().sum((0, 1)))[::-1][:50].tolist()
+                self.session_active_neurons.append(active)
+                if mod == 'ap':
+                    sel = self.session_active_neurons[idx]
+                    res = metrics_list(gt=gt[idx][mod][:, :, sel].transpose(-1, 0), pred=preds[idx][mod][:, :, sel].transpose(-1, 0),
+                                       metrics=["r2"], device=self.accelerator.device)
+                else:
+                    res = metrics_list(gt=gt[idx][mod], pred=preds[idx][mod], metrics=[self.metric], device=self.accelerator.device)
+                scores.append(res[self.metric])
+        return {"eval_loss": eval_loss, f"eval_trial_avg_{self.metric}": np.nanmean(scores), "eval_gt": gt, "eval_preds": preds}
+
+    def plot_epoch(self, gt, preds, epoch, active_neurons, modality):
+        fig = plot_gt_pred(gt=gt.mean(0).T.cpu().numpy(), pred=preds.mean(0).T.detach().cpu().numpy(), epoch=epoch, modality=modality)
+        if modality == 'behavior':
+            active_neurons = range(gt.size()[-1])
+        r2_fig = plot_neurons_r2(gt=gt.mean(0), pred=preds.mean(0), neuron_idx=active_neurons, epoch=epoch)
+        return {"plot_gt_pred": fig, "plot_r2": r2_fig}
+
+    def save_model(self, name="last", epoch=0):
+        """Whole-module pickle like the reference (trainer/base.py:302-308) so its eval scripts can load it."""
+        print(f"saving model: {name} to {self.log_dir}")
+        model = getattr(self.model, "module", self.model)
+        torch.save({"model": model, "epoch": epoch}, os.path.join(self.log_dir, f"model_{name}.pt"))

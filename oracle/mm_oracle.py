@@ -167,6 +167,14 @@ def state_dict_order(sd, cfg: OracleCfg):
     return {k: sd[k] for k in keys}
 
 
+def share_mod_emb(sd, cfg: OracleCfg):
+    """Re-establish share_modality_embeddings (mm.py:84-87) after a state dict was cloned/loaded:
+    the decoder tokenisers' mod_emb must be the SAME tensor object as the encoder's."""
+    for m in cfg.avail_mod:
+        sd[f"decoder_embeddings.{m}.embedder.mod_emb.weight"] = sd[f"encoder_embeddings.{m}.embedder.mod_emb.weight"]
+    return sd
+
+
 def trainable_keys(sd, cfg: OracleCfg) -> List[str]:
     """named_parameters() de-duplicates the shared mod_emb."""
     drop = {f"decoder_embeddings.{m}.embedder.mod_emb.weight" for m in cfg.avail_mod}

@@ -308,10 +308,13 @@ def test_stitch_fwd_bwd(ops):
     ws = torch.empty(64 * (max_F + 1) * H * 8, device="cuda")
     for m in range(M):
         d_tok, d_mod, d_pos = torch.empty(B * T, H, device="cuda"), torch.empty(H, device="cuda"), torch.empty(max_F, H, device="cuda")
-        ops.stitch_bwd(dx, dextra, ts, keep0, None, d_tok, d_mod, d_pos, False, B, T, L, m, H, max_F, ws)
+        ops.stitch_bwd(dx, dextra, ts, keep0, None, d_tok, d_mod, d_pos, False, False, B, T, L, m, H, max_F, ws)
         close(d_tok, toks[m].grad, msg="d_tok")
         close(d_mod, mods[m].grad, atol=1e-4, msg="d_mod")
         close(d_pos, poss[m].grad, atol=1e-4, msg="d_pos")
+        ops.stitch_bwd(dx, dextra, ts, keep0, None, d_tok, d_mod, d_pos, True, False, B, T, L, m, H, max_F, ws)
+        close(d_mod, 2 * mods[m].grad, atol=2e-4, msg="d_mod accumulated")
+        close(d_pos, poss[m].grad, atol=1e-4, msg="d_pos overwritten")
 
 
 @pytest.mark.parametrize("kind,N", [(0, 668), (1, 2), (0, 12)])
