@@ -1,7 +1,224 @@
-// bf16 MFMA GEMM (throughput mode) — see mmfm_gemm in include/mmfm.h.
+// bf16 MFMA GEMM (throughput mode) behind mmfm_gemm: bf16 storage, fp32 accumulate,
+// v_mfma_f32_32x32x16_bf16.  128x128 output tile, BK = 64, 4 wavefronts (2x2), each wave a 64x64
+// sub-tile = 2x2 MFMA tiles (64 accumulator VGPRs); 36 KB of LDS -> up to 4 workgroups per CU, so
+// wave-level parallelism hides the global-load latency of the register-staged prefetch.
+//
+// Two LDS tile images, chosen per operand from its contiguous axis in global memory:
+//   KC (reduction contiguous: x[M,K], W[N,K]):  [128 rows][64 k + 8 pad] bf16, 144-B rows.  The MFMA
+//      operand (8 consecutive k of one row) is one ds_read_b128; the 16-B pad walks consecutive rows
+//      across all sixteen 16-B slots of the 256-B bank row -> conflict-free.
+//   RC (row contiguous: dY^T and X for dW, W for dX):  [64 k][128 rows] bf16, 256-B rows, byte offset
+//      XOR ((k & 3) << 6).  The operand needs 8 k-strided values per lane: two ds_read_b64_tr_b16
+//      (hardware 4x16 transpose); the XOR spreads the four k-rows of a read over the four 64-B quarters
+//      of the bank row -> conflict-free.  Global loads stay 16 B/lane along the contiguous axis.
 #include "common.h"
 
-int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* d, hipStream_t st) {
-    (void)d; (void)st;
-    return mmfm_set_error(-1, "mmfm_gemm: bf16 path not built yet");
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int KC_LD = 72;                   // bf16 elements per LDS row of a KC image
+constexpr int TILE_BYTES = 128 * KC_LD * 2; // 18432 (>= the RC image's 64*256 = 16384)
+constexpr int NTHREADS = 256;
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// 8 consecutive bf16 starting at src, of which the first `nvalid` (<= 8) exist; align = 8/4/1 elements
+__device__ __forceinline__ uint4 load8(const uint16_t* __restrict__ src, int nvalid, int align) {
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (nvalid >= 8 && align == 8) return *reinterpret_cast<const uint4*>(src);
+    if (nvalid >= 8 && align == 4) {
+        const uint2 a = *reinterpret_cast<const uint2*>(src), b = *reinterpret_cast<const uint2*>(src + 4);
+        return make_uint4(a.x, a.y, b.x, b.y);
+    }
+    if (nvalid <= 0) return v;
+    uint16_t e[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) e[j] = (j < nvalid) ? src[j] : (uint16_t)0;
+    v.x = e[0] | ((uint32_t)e[1] << 16); v.y = e[2] | ((uint32_t)e[3] << 16);
+    v.z = e[4] | ((uint32_t)e[5] << 16); v.w = e[6] | ((uint32_t)e[7] << 16);
+    return v;
+}
+
+template <bool RC>
+__device__ __forceinline__ void g2r(uint4 (&r)[4], const uint16_t* __restrict__ base, int ld, int row0, int k0, int rows, int kend,
+                                    int align, int t) {
+    if (!RC) {          // reduction contiguous: 8 lanes x 16 B = one 128-B row segment
+        const int kq = t & 7, r0 = t >> 3, k = k0 + 8 * kq;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int row = row0 + r0 + 32 * p;
+            r[p] = (row < rows) ? load8(base + (size_t)row * ld + k, kend - k, align) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    } else {            // row contiguous: 16 lanes x 16 B = 256 B of one k-row
+        const int cq = t & 15, kk0 = t >> 4, col = row0 + 8 * cq;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int k = k0 + kk0 + 16 * p;
+            r[p] = (k < kend) ? load8(base + (size_t)k * ld + col, rows - col, align) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+}
+
+template <bool RC>
+__device__ __forceinline__ void r2s(char* __restrict__ S, const uint4 (&r)[4], int t) {
+    if (!RC) {
+        const int kq = t & 7, r0 = t >> 3;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(S + (r0 + 32 * p) * (KC_LD * 2) + kq * 16) = r[p];
+    } else {
+        const int cq = t & 15, kk0 = t >> 4;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int kk = kk0 + 16 * p;
+            *reinterpret_cast<uint4*>(S + kk * 256 + ((cq * 16) ^ ((kk & 3) << 6))) = r[p];
+        }
+    }
+}
+
+// MFMA operand for rows [rowbase, rowbase+32) and k in [16*ks, 16*ks+16): lane (r = lane%32, h = lane/32)
+// holds row rowbase + r, k = 16*ks + 8*h + 0..7
+template <bool RC>
+__device__ __forceinline__ bf16x8v frag(const char* __restrict__ S, int rowbase, int ks, int lane) {
+    if (!RC) {
+        const int r = lane & 31, h = lane >> 5;
+        const uint4 v = *reinterpret_cast<const uint4*>(S + (rowbase + r) * (KC_LD * 2) + ks * 32 + h * 16);
+        return __builtin_bit_cast(bf16x8v, v);
+    } else {
+        // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(row) block; lane 4q+p supplies row q's address at
+        // columns 4p..4p+3 and lane i receives column i with the 4 k values in order.
+        const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+        const int col = rowbase + 16 * (g & 1) + 4 * p;
+        const int kb = ks * 16 + 8 * (g >> 1);
+        const int off0 = (kb + q) * 256 + ((col * 2) ^ (q << 6));            // (kb+q) & 3 == q
+        const int off1 = (kb + 4 + q) * 256 + ((col * 2) ^ (q << 6));
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(S + off0));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(S + off1));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v;
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return __builtin_bit_cast(bf16x8v, v);
+    }
+}
+
+template <typename TO>
+__device__ __forceinline__ void epilogue_store(const mmfm_gemm_desc& d, const Drop& dr, float v, int m, int n) {
+    typedef io<uint16_t> I16;
+    if (d.bias) v += d.bias[n];
+    if (d.pre_out) I16::st(reinterpret_cast<uint16_t*>(d.pre_out) + (size_t)m * d.ldc + n, v);
+    if (d.act == 1) v = gelu_erf(v);
+    else if (d.act == 2) v = softsign_f(v) * d.act_scale;
+    if (d.gradmul_pre) {
+        const float u = I16::ld(reinterpret_cast<const uint16_t*>(d.gradmul_pre) + (size_t)m * d.ldc + n);
+        v *= (d.act == 3) ? gelu_erf_grad(u) : softsign_grad(u) * d.act_scale;
+    }
+    v = dr.apply(v, (uint64_t)m * (uint64_t)d.N + (uint64_t)n);
+    if (d.residual) v += I16::ld(reinterpret_cast<const uint16_t*>(d.residual) + (size_t)m * d.ldr + n);
+    io<TO>::st(reinterpret_cast<TO*>(d.C) + (size_t)m * d.ldc + n, v);
+}
+
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
+template <bool ARC, bool BRC, typename TO>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const mmfm_gemm_desc d, const int alignA, const int alignB) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
+    char* As = smem;
+    char* Bs = smem + TILE_BYTES;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, kh = lane >> 5, l31 = lane & 31;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    const int z = blockIdx.y;
+    const int kbeg = z * d.kchunk;
+    const int kend = min(d.K, kbeg + d.kchunk);
+    const uint16_t* A = reinterpret_cast<const uint16_t*>(d.A);
+    const uint16_t* B = reinterpret_cast<const uint16_t*>(d.B);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint4 ra[4], rb[4];
+    g2r<ARC>(ra, A, d.lda, m0, kbeg, d.M, kend, alignA, t);
+    g2r<BRC>(rb, B, d.ldb, n0, kbeg, d.N, kend, alignB, t);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        __syncthreads();
+        r2s<ARC>(As, ra, t);
+        r2s<BRC>(Bs, rb, t);
+        __syncthreads();
+        if (k0 + BK < kend) {
+            g2r<ARC>(ra, A, d.lda, m0, k0 + BK, d.M, kend, alignA, t);
+            g2r<BRC>(rb, B, d.ldb, n0, k0 + BK, d.N, kend, alignB, t);
+        }
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const bf16x8v a0 = frag<ARC>(As, wm * 64, ks, lane), a1 = frag<ARC>(As, wm * 64 + 32, ks, lane);
+            const bf16x8v b0 = frag<BRC>(Bs, wn * 64, ks, lane), b1 = frag<BRC>(Bs, wn * 64 + 32, ks, lane);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+
+    if (d.splits > 1) {
+        float* C = reinterpret_cast<float*>(d.C) + (size_t)z * d.slab_stride;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    const int n = n0 + wn * 64 + j * 32 + l31;
+                    if (m < d.M && n < d.N) C[(size_t)m * d.ldc + n] = acc[i][j][r];
+                }
+        return;
+    }
+    const Drop dr = drop_init(d.drop);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                if (m < d.M && n < d.N) epilogue_store<TO>(d, dr, acc[i][j][r], m, n);
+            }
+}
+
+int align_of(const void* p, int ld) {
+    if (ld % 8 == 0 && (uintptr_t)p % 16 == 0) return 8;
+    if (ld % 4 == 0 && (uintptr_t)p % 8 == 0) return 4;
+    return 1;
+}
+
+}  // namespace
+
+int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
+    const mmfm_gemm_desc d = *dp;
+    MMFM_REQUIRE(d.splits == 1 || d.kchunk % BK == 0, "mmfm_gemm(bf16): kchunk %d must be a multiple of %d", d.kchunk, BK);
+    const int tiles = cdiv(d.M, BM) * cdiv(d.N, BN);
+    const int aA = align_of(d.A, d.lda), aB = align_of(d.B, d.ldb);
+    dim3 grid(tiles, d.splits), block(NTHREADS);
+    const bool f32out = d.c_f32 || d.splits > 1;
+#define LAUNCH(ARC, BRC)                                                                                          \
+    if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float>), grid, block, 0, st, d, aA, aB);            \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t>), grid, block, 0, st, d, aA, aB);
+    if (d.a_kcontig && d.b_kcontig) { LAUNCH(false, false) }
+    else if (d.a_kcontig && !d.b_kcontig) { LAUNCH(false, true) }
+    else { LAUNCH(true, true) }
+#undef LAUNCH
+    MMFM_LAUNCH_CHECK("mmfm_gemm(bf16)");
+    return 0;
 }

@@ -140,16 +140,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, c
     }
 }
 
-__global__ void ln_bwd_finalize(const float* __restrict__ part, int nblk, int H, float* dgamma, float* dbeta, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= 2 * H) return;
+// sum the per-block partials: 64 columns x 4 partial-lanes per block, coalesced along the columns
+__global__ __launch_bounds__(256) void ln_bwd_finalize(const float* __restrict__ part, int nblk, int H, float* dgamma, float* dbeta,
+                                                       int accumulate) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, pl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * 2 * H + c];
-    float* dst = c < H ? dgamma + c : dbeta + (c - H);
-    *dst = accumulate ? *dst + s : s;
+    if (c < 2 * H)
+        for (int b = pl; b < nblk; b += 4) s += part[(size_t)b * 2 * H + c];
+    red[pl][cl] = s;
+    __syncthreads();
+    if (pl == 0 && c < 2 * H) {
+        s = red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl];
+        float* dst = c < H ? dgamma + c : dbeta + (c - H);
+        *dst = accumulate ? *dst + s : s;
+    }
 }
 
-int ln_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (R + 3) / 4)); }
+int ln_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(512, (R + 3) / 4)); }
 
 }  // namespace
 
@@ -193,7 +202,7 @@ extern "C" int mmfm_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     else
         return mmfm_set_error(-1, "mmfm_layernorm_bwd: bad dtype %d", dtype);
     MMFM_LAUNCH_CHECK("mmfm_layernorm_bwd");
-    hipLaunchKernelGGL(ln_bwd_finalize, dim3(cdiv(2 * H, 256)), dim3(256), 0, st, (const float*)workspace, nblk, H, dgamma, dbeta, accumulate);
+    hipLaunchKernelGGL(ln_bwd_finalize, dim3(cdiv(2 * H, 64)), dim3(256), 0, st, (const float*)workspace, nblk, H, dgamma, dbeta, accumulate);
     MMFM_LAUNCH_CHECK("mmfm_layernorm_bwd(finalize)");
     return 0;
 }

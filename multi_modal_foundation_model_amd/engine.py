@@ -261,7 +261,7 @@ class Engine:
     def _dw_split(self, M, N, R):
         tiles = -(-M // 128) * -(-N // 128)
         S = max(1, min(R // 256, max(1, 1024 // tiles)))
-        kchunk = _align(-(-R // S), 32)
+        kchunk = _align(-(-R // S), 64)          # multiple of both kernels' BK (32 fp32, 64 bf16)
         return -(-R // kchunk), kchunk
 
     def _plan(self, B, T, training):

@@ -82,7 +82,7 @@ def test_gemm_dw_splitk(ops, R, N, K, splits):
     if splits == 1:
         ops.gemm(dy, x, dw, N, K, R, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0)
     else:
-        kchunk = ((R + splits - 1) // splits + 31) // 32 * 32
+        kchunk = ((R + splits - 1) // splits + 63) // 64 * 64
         splits = (R + kchunk - 1) // kchunk
         slabs = torch.full((splits, N, K), float("nan"), device="cuda")
         ops.gemm(dy, x, slabs, N, K, R, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0, splits=splits, kchunk=kchunk, slab_stride=N * K)
@@ -91,10 +91,10 @@ def test_gemm_dw_splitk(ops, R, N, K, splits):
 
 
 def test_colsum(ops):
-    for R, N in [(3200, 256), (1001, 668), (64, 2)]:
+    for R, N in [(3200, 256), (1001, 668), (64, 2), (51200, 768), (333, 1336)]:
         x = rnd(R, N, seed=10)
         out = torch.empty(N, device="cuda")
-        ws = torch.empty(64 * N + 16, device="cuda")
+        ws = torch.empty(256 * N + 16, device="cuda")
         ops.colsum(x, R, N, N, out, ws)
         close(out, x.double().sum(0), atol=1e-3, msg="colsum")
         ops.colsum(x, R, N, N, out, ws, accumulate=True)
@@ -383,3 +383,58 @@ def test_gemm_dropout_matches_dropout_apply(ops):
     close(y1[nz], y0[nz] / (1 - p), msg="scaled by 1/(1-p)")
     ops.dropout_apply(y0, y2, M, N, ops.dropout(state, 6, p))
     assert not torch.equal(y1, y2), "different site -> different mask"
+
+
+# ------------------------------------------------------------------------------------ bf16 MFMA GEMM
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def close_bf16(a, b, msg, tol=1.5e-2):
+    a, b = a.float().cpu(), b.float().cpu()
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item() + 1e-6
+    assert err <= tol * scale, f"{msg}: max abs err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 256, 256), (333, 668, 1336), (3200, 768, 256), (1600, 1336, 668), (300, 2, 256), (100, 4, 2), (64, 256, 4)])
+def test_gemm_bf16_linear_forward(ops, M, N, K):
+    x, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3)
+    y = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b)
+    close_bf16(y, x.double() @ w.double().T + b.double(), f"bf16 linear {M}x{N}x{K}")
+
+
+def test_gemm_bf16_epilogues_and_layouts(ops):
+    M, N, K = 500, 512, 256
+    x, w, b, res = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3), bf(rnd(M, N, seed=4))
+    y, pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b, pre_out=pre, act=1, residual=res, ldr=N)
+    u = x.float() @ w.float().T + b
+    close_bf16(pre, u, "bf16 pre_out")
+    close_bf16(y, torch.nn.functional.gelu(u) + res.float(), "bf16 gelu+residual")
+    # dX = dY @ W  (W [K,N] row-contiguous -> transposed LDS reads) with gelu' multiply
+    dy, w2, pr = bf(rnd(M, K, seed=5)), bf(rnd(K, N, seed=6, scale=K ** -0.5)), bf(rnd(M, N, seed=7))
+    dx = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(dy, w2, dx, M, N, K, lda=K, ldb=N, ldc=N, b_kcontig=0)
+    close_bf16(dx, dy.float() @ w2.float(), "bf16 dX")
+    ops.gemm(dy, w2, dx, M, N, K, lda=K, ldb=N, ldc=N, b_kcontig=0, act=3, gradmul_pre=pr)
+    p32 = pr.float().requires_grad_(True)
+    torch.nn.functional.gelu(p32).sum().backward()
+    close_bf16(dx, (dy.float() @ w2.float()) * p32.grad, "bf16 dX*gelu'")
+
+
+@pytest.mark.parametrize("R,N,K,splits", [(3200, 256, 256, 8), (1000, 668, 256, 4), (777, 1336, 668, 3), (640, 2, 256, 2), (3200, 768, 256, 1), (900, 4, 2, 2)])
+def test_gemm_bf16_dw_splitk(ops, R, N, K, splits):
+    dy, x = bf(rnd(R, N, seed=8)), bf(rnd(R, K, seed=9))
+    ref = dy.double().T @ x.double()
+    dw = torch.empty(N, K, device="cuda")
+    if splits == 1:
+        ops.gemm(dy, x, dw, N, K, R, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0, c_f32=1)
+    else:
+        kchunk = ((R + splits - 1) // splits + 63) // 64 * 64
+        splits = (R + kchunk - 1) // kchunk
+        slabs = torch.full((splits, N, K), float("nan"), device="cuda")
+        ops.gemm(dy, x, slabs, N, K, R, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0, splits=splits, kchunk=kchunk, slab_stride=N * K, c_f32=1)
+        ops.reduce_slabs(dw, slabs, N * K, splits, N * K)
+    close_bf16(dw, ref, "bf16 dW", tol=2e-3)          # fp32 accumulate of exact bf16 products

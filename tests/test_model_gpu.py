@@ -240,3 +240,44 @@ def test_checkpoint_pickle_roundtrip(tmp_path):
     m2.masker.ratio = 0.1                                       # eval_utils.py:65-67 mutates these
     with torch.no_grad():
         assert m2(md()).loss.item() == l0
+
+
+# ------------------------------------------------------------------------------------ bf16 throughput mode
+def cosine(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def test_bf16_mode_tracks_fp32_reference_fixture():
+    """bf16 storage / fp32 accumulate vs the fp32 reference numbers: stated tolerance 2e-2 on the loss,
+    gradient direction cosine >= 0.99 per large tensor (bf16 has 8 significant bits)."""
+    g = load_json("default_scalars.json")
+    model = build_model(load_config().model, 668, 2, seed=42)
+    model.compute_dtype = "bf16"
+    model.cuda().eval()
+    ref = build_model(load_config().model, 668, 2, seed=42).cuda().eval()
+    batch = O.synth_batch(16, 100, 668, 2, seed=0)
+    for obj in ("encoding", "decoding"):
+        for m in (model, ref):
+            m.zero_grad(set_to_none=True)
+        out = model(to_dev(O.make_mod_dict(batch, obj)))
+        out.loss.backward()
+        out32 = ref(to_dev(O.make_mod_dict(batch, obj)))
+        out32.loss.backward()
+        assert out.loss.item() == pytest.approx(g[obj]["loss"], rel=2e-2)
+        for mname in ("ap", "behavior"):
+            assert int(out.mod_n_examples[mname]) == g[obj]["n"][mname]
+        p16, p32 = dict(model.named_parameters()), dict(ref.named_parameters())
+        for k in p32:
+            if p32[k].grad.abs().max() > 0 and p32[k].numel() >= 4096:
+                c = cosine(p16[k].grad, p32[k].grad)
+                assert c > 0.99, f"{obj} {k}: cosine {c}"
+
+
+def test_bf16_loss_curve_stays_near_fp32():
+    g = load_json("loss_curve.json")["default"]
+    model = build_model(model_config(dropout=0.0, emb_dropout=0.0), 668, 2, seed=42)
+    model.compute_dtype = "bf16"
+    model.cuda()
+    losses = run_curve(model, 12, 16, 100, 668, 2, 1000, g["objective"])
+    np.testing.assert_allclose(losses, g["loss"][:12], rtol=2e-2)
