@@ -438,3 +438,66 @@ def test_gemm_bf16_dw_splitk(ops, R, N, K, splits):
         ops.gemm(dy, x, slabs, N, K, R, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0, splits=splits, kchunk=kchunk, slab_stride=N * K, c_f32=1)
         ops.reduce_slabs(dw, slabs, N * K, splits, N * K)
     close_bf16(dw, ref, "bf16 dW", tol=2e-3)          # fp32 accumulate of exact bf16 products
+
+
+@pytest.mark.parametrize("B,heads,L,dh,flags", [(2, 8, 200, 32, 1), (2, 8, 200, 32, 0), (2, 4, 48, 16, 2), (2, 4, 40, 16, 4), (2, 2, 70, 64, 1),
+                                                (3, 4, 16, 8, 1)])
+def test_attention_bf16_fwd_bwd(ops, B, heads, L, dh, flags):
+    """bf16 MFMA attention (dh 16/32/64; dh=8 falls through to fp32 compute on bf16 storage) vs an fp32
+    reference on the same bf16-rounded inputs.  Tolerance: bf16 has 8 significant bits."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    H = heads * dh
+    qkv = bf(rnd(B * L, 3 * H, seed=1))
+    d_o = bf(rnd(B * L, H, seed=2))
+    keypad = torch.ones(B, L, dtype=torch.uint8)
+    keypad[0, L - 3:] = 0
+    keypad[1, L // 2: L // 2 + 2] = 0
+    mod_id = (torch.arange(L) >= L // 2).to(torch.uint8)
+    kp, mi = keypad.cuda(), mod_id.cuda()
+    o, lse = torch.empty(B * L, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, L, device="cuda")
+    dqkv = torch.full((B * L, 3 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
+    scale, es, base = 1.0 / math.sqrt(dh), 2, qkv.data_ptr()
+    desc = ops.attn_desc(Lb.BF16, B, heads, L, L, dh, base, base + H * es, base + 2 * H * es, 3 * H, 3 * H, 3 * H, o.data_ptr(), H, lse, kp, mi,
+                         flags, scale, d_o=d_o.data_ptr(), lddo=H, dq=dqkv.data_ptr(), dk=dqkv.data_ptr() + H * es,
+                         dv=dqkv.data_ptr() + 2 * H * es, lddq=3 * H, lddk=3 * H, lddv=3 * H)
+    ops.attn_fwd(desc)
+    ops.attn_bwd(desc)
+    kpb = kp.bool()
+    m = torch.tril(torch.ones(L, L, dtype=torch.bool, device="cuda"))[None].expand(B, L, L) if flags & 2 else kpb[:, None, :].expand(B, L, L)
+    if flags & 1:
+        m = m | torch.eye(L, dtype=torch.bool, device="cuda")[None]
+    if flags & 4:
+        m = m | (mi[None, :, None] != mi[None, None, :])
+    x = qkv.float().requires_grad_(True)
+    q, k, v = [t.view(B, L, heads, dh).transpose(1, 2) for t in x.split(H, dim=1)]
+    oref = ref_attention(q, k, v, m, scale).transpose(1, 2).reshape(B * L, H)
+    close_bf16(o, oref, "bf16 attn fwd", tol=2e-2)
+    s = (q @ k.transpose(-1, -2)) * scale
+    close(lse, torch.logsumexp(s.masked_fill(~m[:, None], float("-inf")), -1), rtol=1e-3, atol=2e-3, msg="bf16 lse")
+    oref.backward(d_o.float())
+    for nm, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
+        close_bf16(dqkv[:, sl], x.grad[:, sl], f"bf16 attn {nm}", tol=3e-2)
+
+
+def test_attention_bf16_dropout_consistency(ops):
+    from multi_modal_foundation_model_amd import _lib as Lb
+    B, heads, L, dh, p = 2, 4, 64, 32, 0.4
+    H = heads * dh
+    qkv = torch.zeros(B * L, 3 * H, device="cuda", dtype=torch.bfloat16)
+    qkv[:, 2 * H:] = 1.0
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 1234)
+    kp = torch.ones(B, L, dtype=torch.uint8, device="cuda")
+    o, lse = torch.empty(B * L, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, L, device="cuda")
+    d_o = torch.ones(B * L, H, device="cuda", dtype=torch.bfloat16)
+    dqkv = torch.empty(B * L, 3 * H, device="cuda", dtype=torch.bfloat16)
+    base, es = qkv.data_ptr(), 2
+    desc = ops.attn_desc(Lb.BF16, B, heads, L, L, dh, base, base + H * es, base + 2 * H * es, 3 * H, 3 * H, 3 * H, o.data_ptr(), H, lse, kp, None, 0,
+                         dh ** -0.5, drop_p=ops.dropout(state, 7, p), d_o=d_o.data_ptr(), lddo=H, dq=dqkv.data_ptr(),
+                         dk=dqkv.data_ptr() + H * es, dv=dqkv.data_ptr() + 2 * H * es, lddq=3 * H, lddk=3 * H, lddv=3 * H)
+    ops.attn_fwd(desc)
+    frac = o.float().view(B, L, heads, dh)[..., 0] * (1 - p)
+    assert abs(frac.mean().item() - (1 - p)) < 0.02 and frac.std().item() > 0.01
+    ops.attn_bwd(desc)
+    dv = dqkv[:, 2 * H:].float().view(B, L, heads, dh)[..., 0]
+    close(dv.sum(1), o.float().view(B, L, heads, dh)[..., 0].sum(1), rtol=2e-2, atol=0.5, msg="bf16 fwd/bwd dropout mask agree")
