@@ -462,7 +462,7 @@ extern "C" int mmfm_attn_fwd(const mmfm_attn_desc* dp, mmfm_stream stream) {
     if (int rc = check_common(d, "mmfm_attn_fwd")) return rc;
     if (d.dtype == MMFM_BF16) {          // bf16 MFMA kernel; shapes it does not take fall through to fp32 compute on bf16 storage
         const int rc = mmfm_attn_bf16_launch(d, false, (hipStream_t)stream);
-        if (rc != 1) return rc;
+        if (rc != -1000) return rc;
     }
     const size_t lds = fwd_lds_bytes(d.Lq, d.Lk, d.dh);
     MMFM_REQUIRE(lds <= 160 * 1024, "mmfm_attn_fwd: Lk=%d dh=%d needs %zu B of LDS (> 160 KiB): key tiling not built yet", d.Lk, d.dh, lds);
@@ -481,7 +481,7 @@ extern "C" int mmfm_attn_bwd(const mmfm_attn_desc* dp, mmfm_stream stream) {
     MMFM_REQUIRE(d.lddo % 4 == 0 && d.lddq % 4 == 0 && d.lddk % 4 == 0 && d.lddv % 4 == 0, "mmfm_attn_bwd: gradient leading dims must be multiples of 4");
     if (d.dtype == MMFM_BF16) {
         const int rc = mmfm_attn_bf16_launch(d, true, (hipStream_t)stream);
-        if (rc != 1) return rc;
+        if (rc != -1000) return rc;
     }
     const size_t lds = bwd_lds_bytes(d.Lq, d.Lk, d.dh);
     MMFM_REQUIRE(lds <= 160 * 1024, "mmfm_attn_bwd: Lq=%d Lk=%d dh=%d needs %zu B of LDS (> 160 KiB): tiling not built yet", d.Lq, d.Lk, d.dh, lds);

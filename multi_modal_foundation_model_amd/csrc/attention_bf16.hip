@@ -62,6 +62,24 @@ struct MaskCtx {
     }
 };
 
+// Dropout on the probabilities, two decisions per hash: element (q, key) uses the low (even key) or high
+// (odd key) 16 bits of hash(pair index), pair index = (bh*Lq + q) * ceil(Lk/2) + key/2.  Forward and both
+// backward phases evaluate the same function, so no mask is stored.
+struct Drop16 {
+    uint32_t k0, k1, t16;
+    float scale;
+    bool on;
+    __device__ __forceinline__ uint32_t hash(uint64_t pidx) const {
+        return mix32(mix32((uint32_t)pidx ^ k0) + k1 + (uint32_t)(pidx >> 32) * 0x9E3779B9u);
+    }
+};
+__device__ __forceinline__ Drop16 drop16_init(mmfm_dropout d) {
+    const Drop b = drop_init(d);
+    Drop16 r;
+    r.k0 = b.k0; r.k1 = b.k1; r.t16 = b.thresh >> 16; r.scale = b.scale; r.on = b.on();
+    return r;
+}
+
 // rows [0,L) x DH bf16 of one head -> LDS image with RS-byte rows and CPR 16-B chunks per row; the rest zero
 template <int DH>
 __device__ __forceinline__ void load_head16(char* __restrict__ dst, int RS, int CPR, const uint16_t* __restrict__ src, int ld, int L, int LP,
@@ -81,12 +99,59 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 // ============================================================================ forward
-template <int DH>
-__global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const mmfm_attn_desc d) {
+// element-wise part of one 32-key x 32-query tile: online softmax + dropout.  FULL = every (q, key) of the tile is
+// valid and allowed (no padding, no causal/sep flags): the mask logic disappears.
+template <bool FULL, bool DROP>
+__device__ __forceinline__ bool fwd_tile(const f32x16& st, float c2, float& m_run, float& l_run, float& alpha, float (&pd)[16], int q,
+                                         int Lq, int Lk, int kt, int kh, const MaskCtx& mk, const Drop16& dp, uint64_t pair_base) {
+    uint32_t okm = 0xffffu;
+    float mx = -INFINITY;
+    if (FULL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+    } else {
+        okm = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kt * 32 + mrow(r, kh);
+            if ((key < Lk) && (q < Lq) && mk.allowed(q, key)) { okm |= 1u << r; mx = fmaxf(mx, st[r]); }
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * c2);                      // c2 > 0
+    if (__all(m_new == -INFINITY)) return false;
+    const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+    alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_use);
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -m_use));
+        float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r + 1], c2, -m_use));
+        if (!FULL) {
+            p0 = (okm >> r) & 1 ? p0 : 0.f;
+            p1 = (okm >> (r + 1)) & 1 ? p1 : 0.f;
+        }
+        ps += p0 + p1;
+        if (DROP) {
+            const uint32_t hsh = dp.hash(pair_base + (uint64_t)((kt * 32 + mrow(r, kh)) >> 1));
+            p0 = (hsh & 0xffffu) >= dp.t16 ? p0 * dp.scale : 0.f;
+            p1 = (hsh >> 16) >= dp.t16 ? p1 * dp.scale : 0.f;
+        }
+        pd[r] = p0;
+        pd[r + 1] = p1;
+    }
+    l_run = l_run * alpha + ps;
+    m_run = m_new;
+    return true;
+}
+
+template <int DH, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_fwd_bf16_kernel(const mmfm_attn_desc d) {
     constexpr int KS = DH / 16, DT = (DH + 31) / 32;
     constexpr int KRS = DH * 2 + 16;          // K rows (row reads)
     constexpr int VRS = DT * 64;              // V rows (transposed reads only), zero padded to 32 columns
     constexpr int SLD = DT * 32 + 1;
+    constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kh = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
@@ -94,28 +159,45 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const mmfm_attn_desc
     char* Ks = smem;
     char* Vs = Ks + LkP * KRS;
     float* Sc = reinterpret_cast<float*>(Vs + LkP * VRS);
-    uint8_t* kpad = reinterpret_cast<uint8_t*>(Sc + 4 * 32 * SLD);
+    int* wflag = reinterpret_cast<int*>(Sc + NW * 32 * SLD);          // [NW] per-wave "all keys valid" votes
+    uint8_t* kpad = reinterpret_cast<uint8_t*>(wflag + NW);
     uint8_t* modl = kpad + LkP;
     const uint16_t* qg = reinterpret_cast<const uint16_t*>(d.q) + (size_t)b * Lq * d.ldq + h * DH;
     const uint16_t* kg = reinterpret_cast<const uint16_t*>(d.k) + (size_t)b * Lk * d.ldk + h * DH;
     const uint16_t* vg = reinterpret_cast<const uint16_t*>(d.v) + (size_t)b * Lk * d.ldv + h * DH;
     uint16_t* og = reinterpret_cast<uint16_t*>(d.o) + (size_t)b * Lq * d.ldo + h * DH;
 
-    load_head16<DH>(Ks, KRS, KRS / 16, kg, d.ldk, Lk, LkP, t, 256);
-    load_head16<DH>(Vs, VRS, VRS / 16, vg, d.ldv, Lk, LkP, t, 256);
-    for (int i = t; i < LkP; i += 256) kpad[i] = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
+    load_head16<DH>(Ks, KRS, KRS / 16, kg, d.ldk, Lk, LkP, t, NT);
+    load_head16<DH>(Vs, VRS, VRS / 16, vg, d.ldv, Lk, LkP, t, NT);
+    int allk = 1;
+    for (int i = t; i < LkP; i += NT) {
+        const uint8_t v = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
+        kpad[i] = v;
+        if (i < Lk) allk &= (v != 0);
+    }
     if (d.flags & MMFM_ATTN_SEP)
-        for (int i = t; i < Lmx; i += 256) modl[i] = d.mod_id[i];
+        for (int i = t; i < Lmx; i += NT) modl[i] = d.mod_id[i];
+    // block-wide AND through the dynamic LDS (no static __shared__: it would shift the 16-B aligned carve-up
+    // and shrink the >64 KB opt-in limit)
+    const int wave_vote = __all(allk) ? 1 : 0;      // all 64 lanes vote BEFORE any divergence
+    if (lane == 0) wflag[wave] = wave_vote;
     __syncthreads();
+    int vote = 1;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) vote &= wflag[w];
+    const bool nomask = vote && !(d.flags & (MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP));
 
     const MaskCtx mk{kpad, modl, d.flags};
-    const Drop dp = drop_init(d.drop_p), dout = drop_init(d.drop_o);
+    const Drop16 dp = drop16_init(d.drop_p);
+    const Drop dout = drop_init(d.drop_o);
     float* sc = Sc + wave * 32 * SLD;
-    const int nqt = (Lq + 31) / 32, nkt = LkP / 32;
+    const int nqt = (Lq + 31) / 32, nkt = LkP / 32, LkH = (Lk + 1) >> 1;
     const float c2 = d.scale * LOG2E;
 
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < nqt; qt += NW) {
         const int q0 = qt * 32, q = q0 + l31;
+        const bool qfull = nomask && (q0 + 32 <= Lq);
+        const uint64_t pair_base = ((uint64_t)blockIdx.x * Lq + (uint64_t)q) * (uint64_t)LkH;
         bf16x8v qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -137,35 +219,23 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const mmfm_attn_desc
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Ks, (kt * 32 + l31) * KRS + ks * 32 + kh * 16), qf[ks], st, 0, 0, 0);
-            float mx = -INFINITY, sv[16];
-            bool ok[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + mrow(r, kh);
-                ok[r] = (key < Lk) && (q < Lq) && mk.allowed(q, key);
-                sv[r] = st[r] * c2;
-                if (ok[r]) mx = fmaxf(mx, sv[r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float m_new = fmaxf(m_run, mx);
-            if (__all(m_new == -INFINITY)) continue;
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_use);
-            float ps = 0.f, pd[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = ok[r] ? __builtin_amdgcn_exp2f(sv[r] - m_use) : 0.f;
-                ps += p;
-                const int key = kt * 32 + mrow(r, kh);
-                pd[r] = dp.apply(p, ((uint64_t)blockIdx.x * Lq + (uint64_t)q) * Lk + (uint64_t)key);
-            }
-            l_run = l_run * alpha + ps;
-            m_run = m_new;
+            float alpha, pd[16];
+            bool live;
+            if (qfull && kt * 32 + 32 <= Lk)
+                live = dp.on ? fwd_tile<true, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base)
+                             : fwd_tile<true, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base);
+            else
+                live = dp.on ? fwd_tile<false, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base)
+                             : fwd_tile<false, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base);
+            if (!live) continue;
             const bf16x8v pf0 = pack8(pd), pf1 = pack8(pd + 8);
+            const bool rescale = !__all(alpha == 1.f);
 #pragma unroll
             for (int i = 0; i < DT; ++i) {
+                if (rescale) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+                }
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, VRS, kt * 32, i * 32, lane), pf0, acc[i], 0, 0, 0);
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, VRS, kt * 32 + 16, i * 32, lane), pf1, acc[i], 0, 0, 0);
             }
@@ -196,7 +266,57 @@ __global__ __launch_bounds__(256) void attn_fwd_bf16_kernel(const mmfm_attn_desc
 }
 
 // ============================================================================ backward
-template <int DH, int NW>
+// Phase A, one half-tile (accumulator rows 8*s2 .. 8*s2+7 = 8 queries, lane = key): P~ (dropped, scaled) and dS.
+template <bool FULL, bool DROP>
+__device__ __forceinline__ void bwdA_half(const f32x16& s, const f32x16& dpv, int s2, float (&pd)[8], float (&ds)[8], float c2, float scale,
+                                          const float* lse2, const float* dlt, int qt, int key, int kh, int Lq, int Lk, const MaskCtx& mk,
+                                          const Drop16& dp, uint64_t pbase, int LkH) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int r = 8 * s2 + e;
+        const int q = qt * 32 + mrow(r, kh);
+        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -lse2[q]));
+        if (!FULL) p = ((q < Lq) && (key < Lk) && mk.allowed(q, key)) ? p : 0.f;
+        float g = dpv[r];
+        float pdrop = p;
+        if (DROP) {
+            const uint32_t hsh = dp.hash((pbase + (uint64_t)q) * (uint64_t)LkH + (uint64_t)(key >> 1));
+            const bool keep = ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= dp.t16;
+            pdrop = keep ? p * dp.scale : 0.f;
+            g = keep ? g * dp.scale : 0.f;
+        }
+        pd[e] = pdrop;
+        ds[e] = p * (g - dlt[q]) * scale;
+    }
+}
+
+// Phase B, one tile (lane = query, accumulator rows = keys): dS^T.
+template <bool FULL, bool DROP>
+__device__ __forceinline__ void bwdB_tile(const f32x16& s, const f32x16& dpv, float (&ds)[16], float c2, float scale, float lq, float dq_,
+                                          int q, int kt, int kh, int Lq, int Lk, const MaskCtx& mk, const Drop16& dp, uint64_t pair_base) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const int key = kt * 32 + mrow(r, kh);
+        float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -lq));
+        float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r + 1], c2, -lq));
+        if (!FULL) {
+            p0 = ((q < Lq) && (key < Lk) && mk.allowed(q, key)) ? p0 : 0.f;
+            p1 = ((q < Lq) && (key + 1 < Lk) && mk.allowed(q, key + 1)) ? p1 : 0.f;
+        }
+        float g0 = dpv[r], g1 = dpv[r + 1];
+        if (DROP) {
+            const uint32_t hsh = dp.hash(pair_base + (uint64_t)(key >> 1));
+            g0 = (hsh & 0xffffu) >= dp.t16 ? g0 * dp.scale : 0.f;
+            g1 = (hsh >> 16) >= dp.t16 ? g1 * dp.scale : 0.f;
+        }
+        ds[r] = p0 * (g0 - dq_) * scale;
+        ds[r + 1] = p1 * (g1 - dq_) * scale;
+    }
+}
+
+// PHASE 0: dK, dV (waves own key tiles)   PHASE 1: dQ (waves own query tiles)   PHASE 2: both in one launch.
+// Two single-phase launches keep each kernel under 256 registers at two waves per SIMD (no spills).
+template <int DH, int NW, int PHASE>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_desc d) {
     constexpr int KS = DH / 16, DT = (DH + 31) / 32;
     constexpr int RS = DH * 2 + 16;
@@ -213,14 +333,16 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
     float* lse2 = reinterpret_cast<float*>(Vs + LkP * RS);    // lse * log2(e)
     float* dlt = lse2 + LqP;
     float* Sc = dlt + LqP;
-    uint8_t* kpad = reinterpret_cast<uint8_t*>(Sc + NW * 32 * SLD);
+    int* wflag = reinterpret_cast<int*>(Sc + NW * 32 * SLD);
+    uint8_t* kpad = reinterpret_cast<uint8_t*>(wflag + NW);
     uint8_t* modl = kpad + LkP;
     const uint16_t* qg = reinterpret_cast<const uint16_t*>(d.q) + (size_t)b * Lq * d.ldq + h * DH;
     const uint16_t* kg = reinterpret_cast<const uint16_t*>(d.k) + (size_t)b * Lk * d.ldk + h * DH;
     const uint16_t* vg = reinterpret_cast<const uint16_t*>(d.v) + (size_t)b * Lk * d.ldv + h * DH;
     const uint16_t* og = reinterpret_cast<const uint16_t*>(d.o) + (size_t)b * Lq * d.ldo + h * DH;
     const uint16_t* dog = reinterpret_cast<const uint16_t*>(d.d_o) + (size_t)b * Lq * d.lddo + h * DH;
-    const Drop dp = drop_init(d.drop_p), dout = drop_init(d.drop_o);
+    const Drop16 dp = drop16_init(d.drop_p);
+    const Drop dout = drop_init(d.drop_o);
 
     load_head16<DH>(Qs, RS, RS / 16, qg, d.ldq, Lq, LqP, t, NT);
     load_head16<DH>(Ks, RS, RS / 16, kg, d.ldk, Lk, LkP, t, NT);
@@ -255,19 +377,31 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
             *reinterpret_cast<uint4*>(dOs + (idx / PADC) * RS + (C8 + idx % PADC) * 16) = make_uint4(0u, 0u, 0u, 0u);
     }
     for (int i = t; i < LqP; i += NT) lse2[i] = (i < Lq) ? d.lse[(size_t)blockIdx.x * Lq + i] * LOG2E : 0.f;
-    for (int i = t; i < LkP; i += NT) kpad[i] = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
+    int allk = 1;
+    for (int i = t; i < LkP; i += NT) {
+        const uint8_t v = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
+        kpad[i] = v;
+        if (i < Lk) allk &= (v != 0);
+    }
     if (d.flags & MMFM_ATTN_SEP)
         for (int i = t; i < Lmx; i += NT) modl[i] = d.mod_id[i];
+    const int wave_vote = __all(allk) ? 1 : 0;      // all 64 lanes vote BEFORE any divergence
+    if (lane == 0) wflag[wave] = wave_vote;
     __syncthreads();
+    int vote = 1;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) vote &= wflag[w];
+    const bool nomask = vote && !(d.flags & (MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP));
 
     const MaskCtx mk{kpad, modl, d.flags};
     float* sc = Sc + wave * 32 * SLD;
-    const int nqt = LqP / 32, nkt = LkP / 32;
+    const int nqt = LqP / 32, nkt = LkP / 32, LkH = (Lk + 1) >> 1;
     const uint64_t pbase = (uint64_t)blockIdx.x * Lq;
     const float c2 = d.scale * LOG2E;
     constexpr int CW = (DH < 32 ? DH : 32) / 4;
 
     // ---------------- phase A: wave owns key tile kt -> dK, dV
+    if constexpr (PHASE != 1)
     for (int kt = wave; kt < nkt; kt += NW) {
         f32x16 dKt[DT], dVt[DT];
 #pragma unroll
@@ -291,25 +425,26 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Qs, off), kfr[ks], s, 0, 0, 0);        // S[q][key]
                 dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(dOs, off), vfr[ks], dpv, 0, 0, 0);   // dP[q][key]
             }
-            float pd[16], ds[16];
+            const bool full = nomask && (kt * 32 + 32 <= Lk) && (qt * 32 + 32 <= Lq);
+            // two half-tiles of 8 accumulator rows each: softmax/dropout algebra, pack to bf16, feed the MFMAs
+            // (keeps only 16 fp32 temporaries live instead of 32)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = qt * 32 + mrow(r, kh);
-                const bool ok = (q < Lq) && (key < Lk) && mk.allowed(q, key);
-                const float p = ok ? __builtin_amdgcn_exp2f(s[r] * c2 - lse2[q]) : 0.f;
-                const bool keep = !dp.on() || dp.keep((pbase + (uint64_t)q) * Lk + (uint64_t)key);
-                pd[r] = keep ? p * dp.scale : 0.f;
-                const float dpd = keep ? dpv[r] * dp.scale : 0.f;
-                ds[r] = p * (dpd - dlt[q]) * d.scale;
-            }
-            const bf16x8v pf[2] = {pack8(pd), pack8(pd + 8)}, sf[2] = {pack8(ds), pack8(ds + 8)};
-#pragma unroll
-            for (int i = 0; i < DT; ++i)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    dVt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(dOs, RS, qt * 32 + 16 * s2, i * 32, lane), pf[s2], dVt[i], 0, 0, 0);
-                    dKt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Qs, RS, qt * 32 + 16 * s2, i * 32, lane), sf[s2], dKt[i], 0, 0, 0);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float pd[8], ds[8];
+                if (full) {
+                    if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
+                    else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
+                } else {
+                    if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
+                    else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
                 }
+                const bf16x8v pf = pack8(pd), sf = pack8(ds);
+#pragma unroll
+                for (int i = 0; i < DT; ++i) {
+                    dVt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(dOs, RS, qt * 32 + 16 * s2, i * 32, lane), pf, dVt[i], 0, 0, 0);
+                    dKt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Qs, RS, qt * 32 + 16 * s2, i * 32, lane), sf, dKt[i], 0, 0, 0);
+                }
+            }
         }
 #pragma unroll
         for (int which = 0; which < 2; ++which) {
@@ -333,6 +468,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
     }
 
     // ---------------- phase B: wave owns query tile qt -> dQ
+    if constexpr (PHASE != 0)
     for (int qt = wave; qt < nqt; qt += NW) {
         f32x16 dQt[DT];
 #pragma unroll
@@ -358,14 +494,14 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
                 dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Vs, off), dofr[ks], dpv, 0, 0, 0);   // dP^T[key][q]
             }
             float ds[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + mrow(r, kh);
-                const bool ok = (q < Lq) && (key < Lk) && mk.allowed(q, key);
-                const float p = ok ? __builtin_amdgcn_exp2f(s[r] * c2 - lq) : 0.f;
-                const bool keep = !dp.on() || dp.keep((pbase + (uint64_t)q) * Lk + (uint64_t)key);
-                const float dpd = keep ? dpv[r] * dp.scale : 0.f;
-                ds[r] = p * (dpd - dq_) * d.scale;
+            const bool full = nomask && (kt * 32 + 32 <= Lk) && (qt * 32 + 32 <= Lq);
+            const uint64_t pair_base = (pbase + (uint64_t)q) * (uint64_t)LkH;
+            if (full) {
+                if (dp.on) bwdB_tile<true, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
+                else bwdB_tile<true, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
+            } else {
+                if (dp.on) bwdB_tile<false, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
+                else bwdB_tile<false, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
             }
             const bf16x8v sf[2] = {pack8(ds), pack8(ds + 8)};
 #pragma unroll
@@ -398,13 +534,14 @@ int bwd_waves() {
     return w;
 }
 
+constexpr int FWD_WAVES = 8;
 size_t fwd_lds(int Lq, int Lk, int dh) {
     const int DT = (dh + 31) / 32, LkP = (Lk + 31) & ~31;
-    return (size_t)LkP * (dh * 2 + 16) + (size_t)LkP * DT * 64 + (size_t)4 * 32 * (DT * 32 + 1) * 4 + LkP + std::max(Lq, Lk) + 16;
+    return (size_t)LkP * (dh * 2 + 16) + (size_t)LkP * DT * 64 + (size_t)FWD_WAVES * 32 * (DT * 32 + 1) * 4 + LkP + std::max(Lq, Lk) + 64;
 }
 size_t bwd_lds(int Lq, int Lk, int dh, int nw) {
     const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31;
-    return (size_t)(2 * LqP + 2 * LkP) * (dh * 2 + 16) + (size_t)2 * LqP * 4 + (size_t)nw * 32 * 33 * 4 + LkP + std::max(Lq, Lk) + 16;
+    return (size_t)(2 * LqP + 2 * LkP) * (dh * 2 + 16) + (size_t)2 * LqP * 4 + (size_t)nw * 32 * 33 * 4 + LkP + std::max(Lq, Lk) + 64;
 }
 
 int opt_in_lds(const void* kern, size_t bytes) {
@@ -421,37 +558,40 @@ int opt_in_lds(const void* kern, size_t bytes) {
 
 }  // namespace
 
-// returns 1 if this path does not handle the shape (caller falls back to the generic kernel), 0 on launch, <0 / hipError on error
+// returns MMFM_NOT_HANDLED (-1000) if this path does not take the shape (the caller falls back to the generic
+// kernel), 0 on launch, otherwise an error code
 int mmfm_attn_bf16_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st) {
-    if (!(d.dh == 16 || d.dh == 32 || d.dh == 64)) return 1;
+    if (!(d.dh == 16 || d.dh == 32 || d.dh == 64)) return -1000;
     const bool al = d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.ldo % 8 == 0 && (uintptr_t)d.q % 16 == 0 &&
                     (uintptr_t)d.k % 16 == 0 && (uintptr_t)d.v % 16 == 0 && (uintptr_t)d.o % 16 == 0;
-    if (!al) return 1;
+    if (!al) return -1000;
     if (backward) {
         const bool alb = d.lddo % 8 == 0 && d.lddq % 4 == 0 && d.lddk % 4 == 0 && d.lddv % 4 == 0 && (uintptr_t)d.d_o % 16 == 0;
-        if (!alb) return 1;
+        if (!alb) return -1000;
         const int nw = bwd_waves();
         const size_t lds = bwd_lds(d.Lq, d.Lk, d.dh, nw);
-        if (lds > 160 * 1024) return 1;
-#define BWD(DHV, NWV)                                                                                             \
+        if (lds > 160 * 1024) return -1000;
+#define BWD1(DHV, NWV, PH)                                                                                        \
         {                                                                                                         \
-            auto kern = attn_bwd_bf16_kernel<DHV, NWV>;                                                           \
+            auto kern = attn_bwd_bf16_kernel<DHV, NWV, PH>;                                                       \
             if (int rc = opt_in_lds(reinterpret_cast<const void*>(kern), lds)) return rc;                         \
             hipLaunchKernelGGL(kern, dim3(d.B * d.heads), dim3(NWV * 64), lds, st, d);                            \
         }
-        if (nw == 8) { if (d.dh == 16) BWD(16, 8) else if (d.dh == 32) BWD(32, 8) else BWD(64, 8) }
-        else { if (d.dh == 16) BWD(16, 4) else if (d.dh == 32) BWD(32, 4) else BWD(64, 4) }
+#define BWD(DHV)                                                                                                  \
+        if (nw == 8) { BWD1(DHV, 8, 0) BWD1(DHV, 8, 1) } else { BWD1(DHV, 4, 2) }
+        if (d.dh == 16) { BWD(16) } else if (d.dh == 32) { BWD(32) } else { BWD(64) }
 #undef BWD
+#undef BWD1
         MMFM_LAUNCH_CHECK("mmfm_attn_bwd(bf16)");
         return 0;
     }
     const size_t lds = fwd_lds(d.Lq, d.Lk, d.dh);
-    if (lds > 160 * 1024) return 1;
+    if (lds > 160 * 1024) return -1000;
 #define FWD(DHV)                                                                                                  \
     {                                                                                                             \
-        auto kern = attn_fwd_bf16_kernel<DHV>;                                                                    \
+        auto kern = attn_fwd_bf16_kernel<DHV, FWD_WAVES>;                                                         \
         if (int rc = opt_in_lds(reinterpret_cast<const void*>(kern), lds)) return rc;                             \
-        hipLaunchKernelGGL(kern, dim3(d.B * d.heads), dim3(256), lds, st, d);                                     \
+        hipLaunchKernelGGL(kern, dim3(d.B * d.heads), dim3(FWD_WAVES * 64), lds, st, d);                          \
     }
     if (d.dh == 16) FWD(16) else if (d.dh == 32) FWD(32) else FWD(64)
 #undef FWD

@@ -118,13 +118,27 @@ __device__ __forceinline__ void epilogue_store(const mmfm_gemm_desc& d, const Dr
     io<TO>::st(reinterpret_cast<TO*>(d.C) + (size_t)m * d.ldc + n, v);
 }
 
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8e;
+__device__ __forceinline__ bf16x8e pack8f(const float* v) {
+    bf16x8e o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)v[e];
+    return o;
+}
+__device__ __forceinline__ void unpack8(uint4 w, float* u) {
+    u[0] = __uint_as_float(w.x << 16); u[1] = __uint_as_float(w.x & 0xffff0000u);
+    u[2] = __uint_as_float(w.y << 16); u[3] = __uint_as_float(w.y & 0xffff0000u);
+    u[4] = __uint_as_float(w.z << 16); u[5] = __uint_as_float(w.z & 0xffff0000u);
+    u[6] = __uint_as_float(w.w << 16); u[7] = __uint_as_float(w.w & 0xffff0000u);
+}
+
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
 template <bool ARC, bool BRC, typename TO>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const mmfm_gemm_desc d, const int alignA, const int alignB) {
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const mmfm_gemm_desc d, const int alignA, const int alignB, const int vec_epi) {
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
     char* As = smem;
     char* Bs = smem + TILE_BYTES;
@@ -170,8 +184,83 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const mmfm_gemm_des
         }
     }
 
-    if (d.splits > 1) {
-        float* C = reinterpret_cast<float*>(d.C) + (size_t)z * d.slab_stride;
+    // ---- epilogue.  Fast path (row-aligned shapes): the fp32 tile is staged through LDS half a tile at a time
+    // (64 rows x 128 cols x 4 B = 32 KB, reusing the operand buffers) so that each thread owns 8 consecutive
+    // columns of a row: bias/pre-activation/residual/output move as 16-B (bf16) or 2x16-B (fp32) accesses.
+    const bool split = d.splits > 1;
+    float* Cf = reinterpret_cast<float*>(d.C) + (split ? (size_t)z * d.slab_stride : 0);
+    const Drop dr = drop_init(d.drop);
+    if (vec_epi) {
+        float* stage = reinterpret_cast<float*>(smem);
+        constexpr int SLDW = 132;
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+            __syncthreads();
+            if (wm == half) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            stage[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * SLDW + wn * 64 + j * 32 + l31] = acc[i][j][r];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int chunk = t + 256 * c, row = chunk >> 4, col = (chunk & 15) * 8;
+                const int m = m0 + half * 64 + row, n = n0 + col;
+                if (m >= d.M || n >= d.N) continue;          // N % 8 == 0 on this path: chunks are all-in or all-out
+                float v[8];
+                const float4 s0 = *reinterpret_cast<const float4*>(stage + row * SLDW + col);
+                const float4 s1 = *reinterpret_cast<const float4*>(stage + row * SLDW + col + 4);
+                v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
+                const size_t off = (size_t)m * d.ldc + n;
+                if (split || sizeof(TO) == 4) {
+                    if (!split && d.bias) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += d.bias[n + e];
+                    }
+                    float* dst = (split ? Cf : reinterpret_cast<float*>(d.C)) + off;
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    continue;
+                }
+                if (d.bias) {
+                    const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n), b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
+                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                }
+                if (d.pre_out) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.pre_out) + off) = __builtin_bit_cast(uint4, pack8f(v));
+                if (d.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+                } else if (d.act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = softsign_f(v[e]) * d.act_scale;
+                }
+                if (d.gradmul_pre) {
+                    float u[8];
+                    unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(d.gradmul_pre) + off), u);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= (d.act == 3) ? gelu_erf_grad(u[e]) : softsign_grad(u[e]) * d.act_scale;
+                }
+                if (dr.on()) {
+                    const uint64_t base = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = dr.keep(base + e) ? v[e] * dr.scale : 0.f;
+                }
+                if (d.residual) {
+                    float u[8];
+                    unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(d.residual) + (size_t)m * d.ldr + n), u);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += u[e];
+                }
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.C) + off) = __builtin_bit_cast(uint4, pack8f(v));
+            }
+        }
+        return;
+    }
+    if (split) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -180,11 +269,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const mmfm_gemm_des
                 for (int r = 0; r < 16; ++r) {
                     const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                     const int n = n0 + wn * 64 + j * 32 + l31;
-                    if (m < d.M && n < d.N) C[(size_t)m * d.ldc + n] = acc[i][j][r];
+                    if (m < d.M && n < d.N) Cf[(size_t)m * d.ldc + n] = acc[i][j][r];
                 }
         return;
     }
-    const Drop dr = drop_init(d.drop);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -212,9 +300,13 @@ int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     const int aA = align_of(d.A, d.lda), aB = align_of(d.B, d.ldb);
     dim3 grid(tiles, d.splits), block(NTHREADS);
     const bool f32out = d.c_f32 || d.splits > 1;
+    // vector epilogue needs 16-B aligned 8-column chunks of every tensor it touches
+    auto al16 = [](const void* p) { return p == nullptr || (uintptr_t)p % 16 == 0; };
+    const int vec = (d.N % 8 == 0) && (d.ldc % 8 == 0) && al16(d.C) && al16(d.pre_out) && al16(d.gradmul_pre) && al16(d.bias) &&
+                    (!d.residual || (d.ldr % 8 == 0 && al16(d.residual))) && (!d.splits || d.splits == 1 || d.slab_stride % 4 == 0);
 #define LAUNCH(ARC, BRC)                                                                                          \
-    if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float>), grid, block, 0, st, d, aA, aB);            \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t>), grid, block, 0, st, d, aA, aB);
+    if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float>), grid, block, 0, st, d, aA, aB, vec);       \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t>), grid, block, 0, st, d, aA, aB, vec);
     if (d.a_kcontig && d.b_kcontig) { LAUNCH(false, false) }
     else if (d.a_kcontig && !d.b_kcontig) { LAUNCH(false, true) }
     else { LAUNCH(true, true) }

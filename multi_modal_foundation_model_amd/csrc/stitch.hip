@@ -45,6 +45,12 @@ __global__ void mask_prep_kernel(MaskSrc src, const int64_t* __restrict__ attn, 
     }
 }
 
+// (a captured hipMemsetAsync node replayed with a stale fill pattern on this stack, so the counters are
+// zeroed by a kernel of our own: plain stream order, identical eager and under hipGraph replay)
+__global__ void zero_u64_kernel(unsigned long long* p, int n) {
+    if ((int)threadIdx.x < n) p[threadIdx.x] = 0ull;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void stitch_fwd_kernel(const T* __restrict__ tok, const float* __restrict__ mod_row,
                                                          const float* __restrict__ pos, const int64_t* __restrict__ ts,
@@ -126,8 +132,8 @@ extern "C" int mmfm_mask_prep(int B, int T, int M, const int64_t* const* mask_sr
         MMFM_REQUIRE(m >= M || (src.p[m] && src.stride[m] > 0), "mmfm_mask_prep: modality %d has no mask source", m);
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(count, 0, sizeof(int64_t) * M, st);
-    if (e != hipSuccess) return mmfm_set_error((int)e, "mmfm_mask_prep: memset: %s", hipGetErrorString(e));
+    hipLaunchKernelGGL(zero_u64_kernel, dim3(1), dim3(64), 0, st, (unsigned long long*)count, M);
+    MMFM_LAUNCH_CHECK("mmfm_mask_prep(zero)");
     const int64_t n = (int64_t)B * M * T;
     hipLaunchKernelGGL(mask_prep_kernel, dim3((int)std::min<int64_t>(256, (n + 255) / 256)), dim3(256), 0, st, src, attn, B, T, M,
                        tokmask, keypad, keep0, mod_id, (unsigned long long*)count);

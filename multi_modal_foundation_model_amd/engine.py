@@ -19,6 +19,7 @@ Reference path: `MultiModal.forward` (src/multi_modal/mm.py:242-308) + autograd 
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
@@ -199,6 +200,9 @@ class Engine:
         self._sites: Dict[str, int] = {}
         self.grad_ready_hooks = []       # DDP: callables(segment_name) fired as backward completes a segment of G
         self.backward_done_hooks = []    # DDP: wait for the collectives (stream-side) before anyone reads G
+        # hipGraph replay of the step plan: the plan neither allocates nor synchronises, so after one eager
+        # (warm-up) run per batch shape it is captured once and replayed.  MMFM_GRAPH=0 disables.
+        self.use_graphs = os.environ.get("MMFM_GRAPH", "1") != "0"
         self.b["loss"] = torch.zeros(1, device=self.device)
         self.b["inv_n"] = torch.zeros(1, device=self.device)
         self.b["gout"] = torch.ones(1, device=self.device)
@@ -225,6 +229,10 @@ class Engine:
         """True while the module's parameters are still views of our flat buffer (e.g. `.to()` breaks it)."""
         lo, hi = self.P.data_ptr(), self.P.data_ptr() + self.P.numel() * 4
         return all(lo <= p.data_ptr() < hi for p in named_params.values())
+
+    def owns_one(self, p) -> bool:
+        lo = self.P.data_ptr()
+        return p.device == self.P.device and lo <= p.data_ptr() < lo + self.P.numel() * 4
 
     def refresh_weights(self):
         """bf16 mode: refresh the bf16 weight copy from the fp32 master (the fused AdamW does it itself)."""
@@ -498,9 +506,26 @@ class Engine:
                      act=L.ACT_SOFTSIGN_GRAD, act_scale=c.embed_scale, gradmul_pre=self.b[f"{side}/z/{m}"])
                 dlin(cur, dz, self.b[f"in/{m}"], p + ".token_embed", BT, n2, n)
         close_segment("embed")
-        plan = dict(fwd=fwd, bwd=bwd, B=B, T=T, training=bool(training), M=M, R=R, BT=BT)
+        plan = dict(fwd=fwd, bwd=bwd, B=B, T=T, training=bool(training), M=M, R=R, BT=BT, runs=dict(fwd=0, bwd=0), graphs={})
         self.plans[key] = plan
         return plan
+
+    def _run(self, plan, which, entries_fn, tag=None):
+        """Run a piece of the plan: eagerly the first time (lazy one-off initialisation such as the >64 KB LDS
+        opt-in must not happen inside a capture), then capture it into a hipGraph and replay."""
+        tag = which if tag is None else tag
+        g = plan["graphs"].get(tag)
+        if g is not None:
+            g.replay()
+            return
+        if not self.use_graphs or plan["runs"][which] < 1:
+            entries_fn()
+            return
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            entries_fn()
+        plan["graphs"][tag] = graph
+        graph.replay()
 
     # ------------------------------------------------------------------ data in
     def load_inputs(self, B, T, inputs, targets, masks, ts, attn):
@@ -516,9 +541,14 @@ class Engine:
     def forward(self, B, T, inputs, targets, masks, ts, attn, training=True, anchor=None):
         plan = self._plan(B, T, training)
         self.load_inputs(B, T, inputs, targets, masks, ts, attn)
-        if training and (self.cfg.dropout > 0 or self.cfg.embed_dropout > 0):
-            K.rng_advance(self.rng)
-        K.run_plan(plan["fwd"])
+        advance = training and (self.cfg.dropout > 0 or self.cfg.embed_dropout > 0)
+
+        def fwd_entries():
+            if advance:
+                K.rng_advance(self.rng)
+            K.run_plan(plan["fwd"])
+        self._run(plan, "fwd", fwd_entries)
+        plan["runs"]["fwd"] += 1
         self._token += 1
         self._fwd_token = self._token
         self._last = plan
@@ -544,11 +574,15 @@ class Engine:
         first = next(iter(self.params.values()), None)
         if first is not None and first.grad is not None:
             accumulate_into = self.G.clone()               # caller did not zero_grad(): keep torch's += semantics
-        for name, seg in self._last["bwd"]:
-            K.run_plan(seg)
-            if accumulate_into is None:
+        plan = self._last
+        if self.grad_ready_hooks and accumulate_into is None:
+            for name, seg in plan["bwd"]:          # DDP: one graph per segment, collectives issued in between
+                self._run(plan, "bwd", lambda seg=seg: K.run_plan(seg), tag="bwd/" + name)
                 for hook in self.grad_ready_hooks:
                     hook(name)
+        else:
+            self._run(plan, "bwd", lambda: [K.run_plan(seg) for _, seg in plan["bwd"]])
+        plan["runs"]["bwd"] += 1
         if accumulate_into is not None:
             self.G.add_(accumulate_into)
             for hook in self.grad_ready_hooks:

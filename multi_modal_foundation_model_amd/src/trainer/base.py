@@ -52,6 +52,10 @@ class MultiModalTrainer():
         else:
             self.training_mode = None
         self.use_wandb = bool(self.config.wandb.use) and wandb is not None
+        # host-side constants of the batch -> mod_dict translation, built once instead of every step: the
+        # modality-index scalars (a pageable H2D copy each = a stream drain per call) and the [B, N] region array
+        self._mod_index_cache = {}
+        self._regions_cache = (None, None)
 
     # ------------------------------------------------------------------ batch -> mod_dict (trainer/base.py:51-103)
     def _forward_model_outputs(self, batch, masking_mode, training_mode):
@@ -65,15 +69,22 @@ class MultiModalTrainer():
 
         mod_dict = {}
         for mod, idx in self.mod_to_indx.items():
+            key = (mod, str(dev))
+            if key not in self._mod_index_cache:
+                self._mod_index_cache[key] = torch.tensor(idx, device=dev)
+            idx_t = self._mod_index_cache[key]
             d = {
-                'inputs_modality': torch.tensor(idx, device=dev), 'targets_modality': torch.tensor(idx, device=dev),
+                'inputs_modality': idx_t, 'targets_modality': idx_t,
                 'inputs_attn_mask': batch['time_attn_mask'], 'inputs_timestamp': batch['spikes_timestamps'],
                 'targets_timestamp': batch['spikes_timestamps'], 'eid': batch['eid'][0],
                 'num_neuron': spikes.shape[2], 'masking_mode': masking_mode,
             }
             if mod == 'ap':
                 d['inputs'], d['targets'] = spikes.clone(), spikes.clone()
-                d['inputs_regions'] = np.asarray(batch['neuron_regions']).T
+                regions = batch['neuron_regions']
+                if self._regions_cache[0] is not regions:          # same session object -> same [B, N] array
+                    self._regions_cache = (regions, np.asarray(regions).T)
+                d['inputs_regions'] = self._regions_cache[1]
             elif mod == 'behavior':
                 d['inputs'], d['targets'] = behav.clone(), behav.clone()
             else:
