@@ -81,7 +81,8 @@ typedef struct {
 } mmfm_gemm_desc;
 int mmfm_gemm(const mmfm_gemm_desc* d, mmfm_stream stream);
 
-/* dst[i] (+)= sum_s src[s*slab_stride + i], fp32, deterministic order. */
+/* dst[i] (+)= sum_s src[s*slab_stride + i], fp32, deterministic order.  `src` is scratch: it may be
+ * clobbered (a tall-skinny reduction first sums groups of slabs in place). */
 int mmfm_reduce_slabs(float* dst, const float* src, int64_t n, int nslabs, int64_t slab_stride,
                       int accumulate, mmfm_stream stream);
 /* out[n] (+)= sum_r x[r*ld + n]   (bias gradients).  workspace >= mmfm_colsum_workspace bytes. */

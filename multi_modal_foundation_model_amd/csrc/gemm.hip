@@ -198,6 +198,48 @@ __global__ void reduce_slabs_kernel(float* __restrict__ dst, const float* __rest
     }
 }
 
+// Bandwidth-shaped slab reduction (n % 4 == 0, 16-B aligned).  A block owns 256 consecutive floats (64 lanes x
+// float4 = 1 KB, one coalesced wave access per slab) and its 4 waves take slabs k = wave, wave+4, ... of the
+// slab group blockIdx.y, two loads in flight each; the 4 partial sums meet in LDS in a fixed order.
+//   INPLACE: the group's sum is written back into the group's first slab (stage 1 of a two-stage reduction)
+template <bool INPLACE>
+__global__ __launch_bounds__(256) void reduce_slabs4_kernel(float* __restrict__ dst, float* __restrict__ src, int64_t n, int nslabs,
+                                                            int64_t stride, int group, int accumulate) {
+    __shared__ float4 red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t i = ((int64_t)blockIdx.x * 64 + lane) * 4;
+    const int k0 = blockIdx.y * group, k1 = min(nslabs, k0 + group);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (i < n) {
+        int k = k0 + wave;
+        for (; k + 4 < k1; k += 8) {
+            const float4 u = *reinterpret_cast<const float4*>(src + (size_t)k * stride + i);
+            const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(k + 4) * stride + i);
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+            b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+        }
+        if (k < k1) {
+            const float4 u = *reinterpret_cast<const float4*>(src + (size_t)k * stride + i);
+            a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        }
+    }
+    red[wave][lane] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    __syncthreads();
+    if (wave == 0 && i < n) {
+        float4 o;
+        o.x = (red[0][lane].x + red[1][lane].x) + (red[2][lane].x + red[3][lane].x);
+        o.y = (red[0][lane].y + red[1][lane].y) + (red[2][lane].y + red[3][lane].y);
+        o.z = (red[0][lane].z + red[1][lane].z) + (red[2][lane].z + red[3][lane].z);
+        o.w = (red[0][lane].w + red[1][lane].w) + (red[2][lane].w + red[3][lane].w);
+        float* out = INPLACE ? src + (size_t)k0 * stride + i : dst + i;
+        if (!INPLACE && accumulate) {
+            const float4 p = *reinterpret_cast<const float4*>(out);
+            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        *reinterpret_cast<float4*>(out) = o;
+    }
+}
+
 // column sums: grid (ceil(N/64), S); block = 64 columns x 4 row lanes
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int64_t R, int N, int ld, float* __restrict__ part,
@@ -291,12 +333,35 @@ extern "C" int mmfm_gemm(const mmfm_gemm_desc* dp, mmfm_stream stream) {
     return 0;
 }
 
-extern "C" int mmfm_reduce_slabs(float* dst, const float* src, int64_t n, int nslabs, int64_t slab_stride,
+// NOTE: `src` is scratch and may be clobbered (the two-stage path sums each slab group into its first slab).
+extern "C" int mmfm_reduce_slabs(float* dst, const float* src_c, int64_t n, int nslabs, int64_t slab_stride,
                                  int accumulate, mmfm_stream stream) {
-    MMFM_REQUIRE(dst && src && n > 0 && nslabs > 0 && slab_stride >= n, "mmfm_reduce_slabs: bad arguments");
-    const int blocks = (int)std::min<int64_t>(2048, (n + 255) / 256);
-    hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dst, src, n, nslabs,
-                       slab_stride, accumulate);
+    MMFM_REQUIRE(dst && src_c && n > 0 && nslabs > 0 && slab_stride >= n, "mmfm_reduce_slabs: bad arguments");
+    float* src = const_cast<float*>(src_c);
+    hipStream_t st = (hipStream_t)stream;
+    const bool vec = (n % 4 == 0) && (slab_stride % 4 == 0) && ((uintptr_t)dst % 16 == 0) && ((uintptr_t)src % 16 == 0);
+    if (!vec) {
+        const int blocks = (int)std::min<int64_t>(2048, (n + 255) / 256);
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(blocks), dim3(256), 0, st, dst, src, n, nslabs, slab_stride, accumulate);
+        MMFM_LAUNCH_CHECK("mmfm_reduce_slabs");
+        return 0;
+    }
+    const int chunks = (int)((n + 255) / 256);
+    // tall-skinny (few chunks, many slabs): split the slabs into groups first so that >= ~512 blocks stream
+    int group = nslabs;
+    if (nslabs >= 16 && chunks < 512) {
+        const int want = std::min(nslabs / 4, std::max(1, 512 / chunks));     // number of groups
+        group = (nslabs + want - 1) / want;
+    }
+    const int ngroups = (nslabs + group - 1) / group;
+    if (ngroups > 1) {
+        hipLaunchKernelGGL(reduce_slabs4_kernel<true>, dim3(chunks, ngroups), dim3(256), 0, st, dst, src, n, nslabs, slab_stride, group, 0);
+        MMFM_LAUNCH_CHECK("mmfm_reduce_slabs(stage 1)");
+        hipLaunchKernelGGL(reduce_slabs4_kernel<false>, dim3(chunks, 1), dim3(256), 0, st, dst, src, n, ngroups, slab_stride * group, ngroups,
+                           accumulate);
+    } else {
+        hipLaunchKernelGGL(reduce_slabs4_kernel<false>, dim3(chunks, 1), dim3(256), 0, st, dst, src, n, nslabs, slab_stride, nslabs, accumulate);
+    }
     MMFM_LAUNCH_CHECK("mmfm_reduce_slabs");
     return 0;
 }

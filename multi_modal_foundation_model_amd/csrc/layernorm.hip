@@ -158,9 +158,14 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize(const float* __restrict__
     }
 }
 
-int ln_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(512, (R + 3) / 4)); }
+// enough workgroups to fill every wave slot of the chip (256 CUs x 8 blocks of 4 waves): streaming kernels
+// hide HBM latency with waves in flight; the backward keeps fewer blocks (its per-block partials are reduced after)
+int ln_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(2048, (R + 3) / 4)); }
+int ln_bwd_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (R + 3) / 4)); }
 
 }  // namespace
+
+extern "C" int mmfm_reduce_slabs(float*, const float*, int64_t, int, int64_t, int, mmfm_stream);
 
 extern "C" int mmfm_layernorm_fwd(int dtype, const void* x, const float* gamma, const float* beta, void* y,
                                   float* mean, float* rstd, int64_t R, int H, float eps, int dsL, int dsT,
@@ -180,7 +185,7 @@ extern "C" int mmfm_layernorm_fwd(int dtype, const void* x, const float* gamma, 
     return 0;
 }
 
-extern "C" int64_t mmfm_layernorm_bwd_workspace(int64_t R, int H) { return (int64_t)ln_blocks(R) * 2 * H * sizeof(float); }
+extern "C" int64_t mmfm_layernorm_bwd_workspace(int64_t R, int H) { return (int64_t)ln_bwd_blocks(R) * 2 * H * sizeof(float); }
 
 extern "C" int mmfm_layernorm_bwd(int dtype, const void* dy, const void* x, const float* mean, const float* rstd,
                                   const float* gamma, const void* dres, void* dx, float* dgamma, float* dbeta,
@@ -190,7 +195,7 @@ extern "C" int mmfm_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     MMFM_REQUIRE(R > 0 && H > 0 && H % 4 == 0 && H <= 1024, "mmfm_layernorm_bwd: H=%d must be a multiple of 4, <= 1024", H);
     MMFM_REQUIRE(dsT == 0 || (dsL > 0 && dsL % dsT == 0 && R % dsL == 0), "mmfm_layernorm_bwd: bad destitch");
     MMFM_REQUIRE(workspace && workspace_bytes >= mmfm_layernorm_bwd_workspace(R, H), "mmfm_layernorm_bwd: workspace too small");
-    const int nblk = ln_blocks(R);
+    const int nblk = ln_bwd_blocks(R);
     const size_t lds = (size_t)4 * 2 * H * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MMFM_F32)
@@ -202,7 +207,7 @@ extern "C" int mmfm_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     else
         return mmfm_set_error(-1, "mmfm_layernorm_bwd: bad dtype %d", dtype);
     MMFM_LAUNCH_CHECK("mmfm_layernorm_bwd");
-    hipLaunchKernelGGL(ln_bwd_finalize, dim3(cdiv(2 * H, 64)), dim3(256), 0, st, (const float*)workspace, nblk, H, dgamma, dbeta, accumulate);
-    MMFM_LAUNCH_CHECK("mmfm_layernorm_bwd(finalize)");
-    return 0;
+    // per-block partials [nblk][2][H] -> dgamma, dbeta (two tall-skinny slab reductions)
+    if (int rc = mmfm_reduce_slabs(dgamma, (const float*)workspace, H, nblk, 2 * (int64_t)H, accumulate, stream)) return rc;
+    return mmfm_reduce_slabs(dbeta, (const float*)workspace + H, H, nblk, 2 * (int64_t)H, accumulate, stream);
 }

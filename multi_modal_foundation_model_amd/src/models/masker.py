@@ -18,6 +18,35 @@ import torch.nn.functional as F
 TOKEN_MODES = ("temporal", "random_token", "causal")
 
 
+class _PinnedRing:
+    """Asynchronous host->device copies of small tensors.  `t.to(device)` from pageable memory is a synchronous
+    copy that drains the stream (a ~5 ms stall per call once the GPU runs ahead); staging through pinned
+    buffers makes it truly asynchronous.  A slot is reused only after the copy that last read it completed."""
+
+    def __init__(self, slots=8):
+        self.slots, self.i, self.bufs, self.events = slots, 0, {}, {}
+
+    def to(self, t, device):
+        device = torch.device(device)
+        if device.type != "cuda" or t.is_cuda:
+            return t.to(device)
+        key = (tuple(t.shape), t.dtype)
+        if key not in self.bufs:
+            self.bufs[key] = [torch.empty(t.shape, dtype=t.dtype).pin_memory() for _ in range(self.slots)]
+            self.events[key] = [None] * self.slots
+        self.i = (self.i + 1) % self.slots
+        ev = self.events[key][self.i]
+        if ev is not None:
+            ev.synchronize()
+        buf = self.bufs[key][self.i]
+        buf.copy_(t)
+        out = buf.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[key][self.i] = ev
+        return out
+
+
 class Masker(nn.Module):
 
     def __init__(self, config):
@@ -39,6 +68,12 @@ class Masker(nn.Module):
         # corrupted spikes, so only the token-level draw matters.  Skipping the three full-size draws
         # changes the generator stream (masks stay identically distributed, not bit-identical).
         self.token_mask_only = False
+        self._ring = _PinnedRing()
+
+    def __getstate__(self):                    # checkpoints pickle the whole model: drop pinned buffers / events
+        state = self.__dict__.copy()
+        state["_ring"] = None
+        return state
 
     @staticmethod
     def _no_mask(spikes):
@@ -94,7 +129,9 @@ class Masker(nn.Module):
         else:
             raise Exception(f"Masking mode {self.mode} not implemented")
 
-        drawn = torch.bernoulli(probs).to(dev)
+        if self._ring is None:
+            self._ring = _PinnedRing()
+        drawn = self._ring.to(torch.bernoulli(probs), dev)
         causal_target = None
         if self.mode in TOKEN_MODES:
             if timespan > 1:
