@@ -63,14 +63,23 @@ struct MaskCtx {
 };
 
 // Dropout on the probabilities, two decisions per hash: element (q, key) uses the low (even key) or high
-// (odd key) 16 bits of hash(pair index), pair index = (bh*Lq + q) * ceil(Lk/2) + key/2.  Forward and both
+// (odd key) 16 bits of hash(pair index), pair index = (bh*Lq + q) * ceil(Lk/2) + key/2 (mod 2^32).  Forward and both
 // backward phases evaluate the same function, so no mask is stored.
 struct Drop16 {
     uint32_t k0, k1, t16;
     float scale;
     bool on;
-    __device__ __forceinline__ uint32_t hash(uint64_t pidx) const {
-        return mix32(mix32((uint32_t)pidx ^ k0) + k1 + (uint32_t)(pidx >> 32) * 0x9E3779B9u);
+    // xorshift / 24-bit-multiply mixer: v_mul_u32_u24 issues at the full VALU rate, v_mul_lo_u32 at a quarter
+    // of it, and the probabilities need ~10^9 decisions per step.  Each xorshift folds the bits the next 24-bit
+    // multiply would drop back into its low 24 bits.
+    __device__ __forceinline__ uint32_t hash(uint32_t pidx) const {
+        uint32_t h = pidx ^ k0;
+        h ^= h >> 16;
+        h = __umul24(h, 0x7FEB35u) + k1;
+        h ^= h >> 13;
+        h = __umul24(h, 0x46CA6Bu) ^ (h >> 9);
+        h ^= h >> 16;
+        return h;
     }
 };
 __device__ __forceinline__ Drop16 drop16_init(mmfm_dropout d) {
@@ -103,7 +112,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // valid and allowed (no padding, no causal/sep flags): the mask logic disappears.
 template <bool FULL, bool DROP>
 __device__ __forceinline__ bool fwd_tile(const f32x16& st, float c2, float& m_run, float& l_run, float& alpha, float (&pd)[16], int q,
-                                         int Lq, int Lk, int kt, int kh, const MaskCtx& mk, const Drop16& dp, uint64_t pair_base) {
+                                         int Lq, int Lk, int kt, int kh, const MaskCtx& mk, const Drop16& dp, uint32_t pair_base) {
     uint32_t okm = 0xffffu;
     float mx = -INFINITY;
     if (FULL) {
@@ -133,7 +142,7 @@ __device__ __forceinline__ bool fwd_tile(const f32x16& st, float c2, float& m_ru
         }
         ps += p0 + p1;
         if (DROP) {
-            const uint32_t hsh = dp.hash(pair_base + (uint64_t)((kt * 32 + mrow(r, kh)) >> 1));
+            const uint32_t hsh = dp.hash(pair_base + (uint32_t)((kt * 32 + mrow(r, kh)) >> 1));
             p0 = (hsh & 0xffffu) >= dp.t16 ? p0 * dp.scale : 0.f;
             p1 = (hsh >> 16) >= dp.t16 ? p1 * dp.scale : 0.f;
         }
@@ -145,8 +154,10 @@ __device__ __forceinline__ bool fwd_tile(const f32x16& st, float c2, float& m_ru
     return true;
 }
 
+// __launch_bounds__ second argument = waves per SIMD the register allocation must allow: 3 -> <= 168 VGPRs, so three
+// 4-wave workgroups (49 KB of LDS each at L = 200, dh = 32) co-reside on a CU
 template <int DH, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_fwd_bf16_kernel(const mmfm_attn_desc d) {
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel(const mmfm_attn_desc d) {
     constexpr int KS = DH / 16, DT = (DH + 31) / 32;
     constexpr int KRS = DH * 2 + 16;          // K rows (row reads)
     constexpr int VRS = DT * 64;              // V rows (transposed reads only), zero padded to 32 columns
@@ -197,7 +208,8 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_bf16_kernel(const mmfm_attn_
     for (int qt = wave; qt < nqt; qt += NW) {
         const int q0 = qt * 32, q = q0 + l31;
         const bool qfull = nomask && (q0 + 32 <= Lq);
-        const uint64_t pair_base = ((uint64_t)blockIdx.x * Lq + (uint64_t)q) * (uint64_t)LkH;
+        // 32-bit pair index (wraps identically in the forward and both backward phases for very large batches)
+        const uint32_t pair_base = ((uint32_t)blockIdx.x * (uint32_t)Lq + (uint32_t)q) * (uint32_t)LkH;
         bf16x8v qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -212,13 +224,21 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_bf16_kernel(const mmfm_attn_
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-        for (int kt = 0; kt < nkt; ++kt) {
-            f32x16 st;
+        // S^T of tile kt+1 is issued before the softmax of tile kt: the matrix pipe works under the VALU-heavy
+        // softmax instead of stalling it at the top of every iteration
+        auto score = [&](int kt) {
+            f32x16 acc_s;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) st[r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc_s[r] = 0.f;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
-                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Ks, (kt * 32 + l31) * KRS + ks * 32 + kh * 16), qf[ks], st, 0, 0, 0);
+                acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Ks, (kt * 32 + l31) * KRS + ks * 32 + kh * 16), qf[ks], acc_s, 0, 0, 0);
+            return acc_s;
+        };
+        f32x16 st_next = score(0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const f32x16 st = st_next;
+            if (kt + 1 < nkt) st_next = score(kt + 1);
             float alpha, pd[16];
             bool live;
             if (qfull && kt * 32 + 32 <= Lk)
@@ -270,7 +290,7 @@ __global__ __launch_bounds__(NW * 64) void attn_fwd_bf16_kernel(const mmfm_attn_
 template <bool FULL, bool DROP>
 __device__ __forceinline__ void bwdA_half(const f32x16& s, const f32x16& dpv, int s2, float (&pd)[8], float (&ds)[8], float c2, float scale,
                                           const float* lse2, const float* dlt, int qt, int key, int kh, int Lq, int Lk, const MaskCtx& mk,
-                                          const Drop16& dp, uint64_t pbase, int LkH) {
+                                          const Drop16& dp, uint32_t pbase, int LkH) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int r = 8 * s2 + e;
@@ -280,7 +300,7 @@ __device__ __forceinline__ void bwdA_half(const f32x16& s, const f32x16& dpv, in
         float g = dpv[r];
         float pdrop = p;
         if (DROP) {
-            const uint32_t hsh = dp.hash((pbase + (uint64_t)q) * (uint64_t)LkH + (uint64_t)(key >> 1));
+            const uint32_t hsh = dp.hash((pbase + (uint32_t)q) * (uint32_t)LkH + (uint32_t)(key >> 1));
             const bool keep = ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= dp.t16;
             pdrop = keep ? p * dp.scale : 0.f;
             g = keep ? g * dp.scale : 0.f;
@@ -293,7 +313,7 @@ __device__ __forceinline__ void bwdA_half(const f32x16& s, const f32x16& dpv, in
 // Phase B, one tile (lane = query, accumulator rows = keys): dS^T.
 template <bool FULL, bool DROP>
 __device__ __forceinline__ void bwdB_tile(const f32x16& s, const f32x16& dpv, float (&ds)[16], float c2, float scale, float lq, float dq_,
-                                          int q, int kt, int kh, int Lq, int Lk, const MaskCtx& mk, const Drop16& dp, uint64_t pair_base) {
+                                          int q, int kt, int kh, int Lq, int Lk, const MaskCtx& mk, const Drop16& dp, uint32_t pair_base) {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
         const int key = kt * 32 + mrow(r, kh);
@@ -305,7 +325,7 @@ __device__ __forceinline__ void bwdB_tile(const f32x16& s, const f32x16& dpv, fl
         }
         float g0 = dpv[r], g1 = dpv[r + 1];
         if (DROP) {
-            const uint32_t hsh = dp.hash(pair_base + (uint64_t)(key >> 1));
+            const uint32_t hsh = dp.hash(pair_base + (uint32_t)(key >> 1));
             g0 = (hsh & 0xffffu) >= dp.t16 ? g0 * dp.scale : 0.f;
             g1 = (hsh >> 16) >= dp.t16 ? g1 * dp.scale : 0.f;
         }
@@ -314,26 +334,59 @@ __device__ __forceinline__ void bwdB_tile(const f32x16& s, const f32x16& dpv, fl
     }
 }
 
-// PHASE 0: dK, dV (waves own key tiles)   PHASE 1: dQ (waves own query tiles)   PHASE 2: both in one launch.
-// Two single-phase launches keep each kernel under 256 registers at two waves per SIMD (no spills).
+// Accumulator tile (rows = head dim d, lane = token) -> bf16 rows [token][d] written IN PLACE into the wave's own,
+// already consumed 32-row tile of an LDS image (RS-byte rows), then streamed to global as 16-B row chunks.
+template <int DH, int DT>
+__device__ __forceinline__ void store_tile_T(char* tile, int RS, const f32x16 (&acc)[DT], uint16_t* outg, int ld, int row0, int nrows_total,
+                                             int lane) {
+    const int l31 = lane & 31, kh = lane >> 5;
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int dcol = i * 32 + 8 * g + 4 * kh;
+            if (dcol < DH) {
+                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
+                bf16x4v v;
+                v[0] = (__bf16)acc[i][4 * g + 0]; v[1] = (__bf16)acc[i][4 * g + 1];
+                v[2] = (__bf16)acc[i][4 * g + 2]; v[3] = (__bf16)acc[i][4 * g + 3];
+                *reinterpret_cast<uint2*>(tile + l31 * RS + dcol * 2) = __builtin_bit_cast(uint2, v);
+            }
+        }
+    wave_lds_fence();
+    constexpr int C8 = DH / 8;
+    for (int idx = lane; idx < 32 * C8; idx += 64) {
+        const int row = idx / C8, c = idx % C8;
+        if (row0 + row < nrows_total)
+            *reinterpret_cast<uint4*>(outg + (size_t)(row0 + row) * ld + 8 * c) = *reinterpret_cast<const uint4*>(tile + row * RS + c * 16);
+    }
+}
+
+// PHASE 0: dK, dV (waves own key tiles)   PHASE 1: dQ (waves own query tiles).  Two launches, each with only
+// the operands it shares between waves in LDS:
+//   phase 0: Q and dO of the head (row reads for S/dP, transposed reads for dV^T/dK^T) + lse, delta; the wave's own
+//            K/V tile goes from global memory straight into registers;
+//   phase 1: K and V (row reads for S^T/dP^T, transposed K for dQ^T); the wave's own Q/dO rows go straight into
+//            registers, delta = rowsum(d_o * o) is a per-lane dot product.
+// ~48 KB of LDS per 4-wave workgroup -> three workgroups per CU, which is what hides each one's load prologue.
 template <int DH, int NW, int PHASE>
 __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_desc d) {
     constexpr int KS = DH / 16, DT = (DH + 31) / 32;
     constexpr int RS = DH * 2 + 16;
-    constexpr int SLD = 33;
     constexpr int NT = NW * 64;
+    constexpr int C8 = DH / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kh = lane >> 5, l31 = lane & 31;
     const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
     const int Lq = d.Lq, Lk = d.Lk, LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31, Lmx = max(Lq, Lk);
-    char* Qs = smem;
-    char* dOs = Qs + LqP * RS;
-    char* Ks = dOs + LqP * RS;
-    char* Vs = Ks + LkP * RS;
-    float* lse2 = reinterpret_cast<float*>(Vs + LkP * RS);    // lse * log2(e)
-    float* dlt = lse2 + LqP;
-    float* Sc = dlt + LqP;
-    int* wflag = reinterpret_cast<int*>(Sc + NW * 32 * SLD);
+    const int LA = PHASE == 0 ? LqP : LkP;            // rows of the two shared images
+    char* As = smem;                                  // phase 0: Q        phase 1: K
+    char* Bs = As + LA * RS;                          // phase 0: dO       phase 1: V
+    float* lse2 = reinterpret_cast<float*>(Bs + LA * RS);     // phase 0 only: lse * log2(e), [LqP]
+    float* dlt = lse2 + (PHASE == 0 ? LqP : 0);               // phase 0 only: delta, [LqP]
+    char* Sc = reinterpret_cast<char*>(dlt + (PHASE == 0 ? LqP : 0));   // [NW][32 rows x RS] bf16 transpose tiles
+    int* wflag = reinterpret_cast<int*>(Sc + NW * 32 * RS);
     uint8_t* kpad = reinterpret_cast<uint8_t*>(wflag + NW);
     uint8_t* modl = kpad + LkP;
     const uint16_t* qg = reinterpret_cast<const uint16_t*>(d.q) + (size_t)b * Lq * d.ldq + h * DH;
@@ -344,11 +397,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
     const Drop16 dp = drop16_init(d.drop_p);
     const Drop dout = drop_init(d.drop_o);
 
-    load_head16<DH>(Qs, RS, RS / 16, qg, d.ldq, Lq, LqP, t, NT);
-    load_head16<DH>(Ks, RS, RS / 16, kg, d.ldk, Lk, LkP, t, NT);
-    load_head16<DH>(Vs, RS, RS / 16, vg, d.ldv, Lk, LkP, t, NT);
-    {   // dO = dropout'(d_o) as bf16;  delta = rowsum(d_o * o)
-        constexpr int C8 = DH / 8;
+    if constexpr (PHASE == 0) {
+        load_head16<DH>(As, RS, RS / 16, qg, d.ldq, Lq, LqP, t, NT);
+        // dO = dropout'(d_o) as bf16;  delta = rowsum(d_o * o)
         for (int idx = t; idx < LqP * C8; idx += NT) {
             const int row = idx / C8, c = idx % C8;
             uint4 g = make_uint4(0u, 0u, 0u, 0u), o = g;
@@ -370,13 +421,16 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
 #pragma unroll
             for (int off = 1; off < C8; off <<= 1) part += __shfl_xor(part, off);
             if (c == 0) dlt[row] = part;
-            *reinterpret_cast<uint4*>(dOs + row * RS + c * 16) = __builtin_bit_cast(uint4, pack8(gd));
+            *reinterpret_cast<uint4*>(Bs + row * RS + c * 16) = __builtin_bit_cast(uint4, pack8(gd));
         }
-        constexpr int PADC = RS / 16 - C8;           // zero the pad chunk(s) of dOs rows
+        constexpr int PADC = RS / 16 - C8;
         for (int idx = t; idx < LqP * PADC; idx += NT)
-            *reinterpret_cast<uint4*>(dOs + (idx / PADC) * RS + (C8 + idx % PADC) * 16) = make_uint4(0u, 0u, 0u, 0u);
+            *reinterpret_cast<uint4*>(Bs + (idx / PADC) * RS + (C8 + idx % PADC) * 16) = make_uint4(0u, 0u, 0u, 0u);
+        for (int i = t; i < LqP; i += NT) lse2[i] = (i < Lq) ? d.lse[(size_t)blockIdx.x * Lq + i] * LOG2E : 0.f;
+    } else {
+        load_head16<DH>(As, RS, RS / 16, kg, d.ldk, Lk, LkP, t, NT);
+        load_head16<DH>(Bs, RS, RS / 16, vg, d.ldv, Lk, LkP, t, NT);
     }
-    for (int i = t; i < LqP; i += NT) lse2[i] = (i < Lq) ? d.lse[(size_t)blockIdx.x * Lq + i] * LOG2E : 0.f;
     int allk = 1;
     for (int i = t; i < LkP; i += NT) {
         const uint8_t v = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
@@ -394,14 +448,13 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
     const bool nomask = vote && !(d.flags & (MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP));
 
     const MaskCtx mk{kpad, modl, d.flags};
-    float* sc = Sc + wave * 32 * SLD;
     const int nqt = LqP / 32, nkt = LkP / 32, LkH = (Lk + 1) >> 1;
-    const uint64_t pbase = (uint64_t)blockIdx.x * Lq;
+    const uint32_t pbase = (uint32_t)blockIdx.x * (uint32_t)Lq;
     const float c2 = d.scale * LOG2E;
-    constexpr int CW = (DH < 32 ? DH : 32) / 4;
+    char* sct = Sc + wave * 32 * RS;
 
-    // ---------------- phase A: wave owns key tile kt -> dK, dV
-    if constexpr (PHASE != 1)
+    // ---------------- phase 0: wave owns key tile kt -> dK, dV          (As = Q image, Bs = dO image)
+    if constexpr (PHASE == 0)
     for (int kt = wave; kt < nkt; kt += NW) {
         f32x16 dKt[DT], dVt[DT];
 #pragma unroll
@@ -412,22 +465,32 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
         bf16x8v kfr[KS], vfr[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            kfr[ks] = rowfrag(Ks, (kt * 32 + l31) * RS + ks * 32 + kh * 16);
-            vfr[ks] = rowfrag(Vs, (kt * 32 + l31) * RS + ks * 32 + kh * 16);
+            uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
+            if (key < Lk) {
+                kv = *reinterpret_cast<const uint4*>(kg + (size_t)key * d.ldk + ks * 16 + 8 * kh);
+                vv = *reinterpret_cast<const uint4*>(vg + (size_t)key * d.ldv + ks * 16 + 8 * kh);
+            }
+            kfr[ks] = __builtin_bit_cast(bf16x8v, kv);
+            vfr[ks] = __builtin_bit_cast(bf16x8v, vv);
         }
-        for (int qt = 0; qt < nqt; ++qt) {
-            f32x16 s, dpv;
+        // S and dP of query tile qt+1 are issued before the element-wise work of tile qt (matrix pipe under VALU)
+        f32x16 s_next, dp_next;
+        auto scoresA = [&](int qt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dpv[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { s_next[r] = 0.f; dp_next[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int off = (qt * 32 + l31) * RS + ks * 32 + kh * 16;
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Qs, off), kfr[ks], s, 0, 0, 0);        // S[q][key]
-                dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(dOs, off), vfr[ks], dpv, 0, 0, 0);   // dP[q][key]
+                s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(As, off), kfr[ks], s_next, 0, 0, 0);        // S[q][key]
+                dp_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Bs, off), vfr[ks], dp_next, 0, 0, 0);     // dP[q][key]
             }
+        };
+        scoresA(0);
+        for (int qt = 0; qt < nqt; ++qt) {
+            const f32x16 s = s_next, dpv = dp_next;
+            if (qt + 1 < nqt) scoresA(qt + 1);
             const bool full = nomask && (kt * 32 + 32 <= Lk) && (qt * 32 + 32 <= Lq);
             // two half-tiles of 8 accumulator rows each: softmax/dropout algebra, pack to bf16, feed the MFMAs
-            // (keeps only 16 fp32 temporaries live instead of 32)
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 float pd[8], ds[8];
@@ -441,34 +504,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
                 const bf16x8v pf = pack8(pd), sf = pack8(ds);
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
-                    dVt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(dOs, RS, qt * 32 + 16 * s2, i * 32, lane), pf, dVt[i], 0, 0, 0);
-                    dKt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Qs, RS, qt * 32 + 16 * s2, i * 32, lane), sf, dKt[i], 0, 0, 0);
+                    dVt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Bs, RS, qt * 32 + 16 * s2, i * 32, lane), pf, dVt[i], 0, 0, 0);
+                    dKt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(As, RS, qt * 32 + 16 * s2, i * 32, lane), sf, dKt[i], 0, 0, 0);
                 }
             }
         }
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const int ldo_ = which ? d.lddv : d.lddk;
-            uint16_t* outg = reinterpret_cast<uint16_t*>(which ? d.dv : d.dk) + (size_t)b * Lk * ldo_ + h * DH;
-#pragma unroll
-            for (int i = 0; i < DT; ++i) {
-                wave_lds_fence();
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[l31 * SLD + mrow(r, kh)] = which ? dVt[i][r] : dKt[i][r];
-                wave_lds_fence();
-                for (int idx = lane; idx < 32 * CW; idx += 64) {
-                    const int row = idx / CW, c = idx % CW;
-                    if (kt * 32 + row < Lk) {
-                        const float* p = sc + row * SLD + 4 * c;
-                        io<uint16_t>::st4(outg + (size_t)(kt * 32 + row) * ldo_ + i * 32 + 4 * c, make_float4(p[0], p[1], p[2], p[3]));
-                    }
-                }
-            }
-        }
+        store_tile_T<DH, DT>(sct, RS, dKt, reinterpret_cast<uint16_t*>(d.dk) + (size_t)b * Lk * d.lddk + h * DH, d.lddk, kt * 32, Lk, lane);
+        store_tile_T<DH, DT>(sct, RS, dVt, reinterpret_cast<uint16_t*>(d.dv) + (size_t)b * Lk * d.lddv + h * DH, d.lddv, kt * 32, Lk, lane);
     }
 
-    // ---------------- phase B: wave owns query tile qt -> dQ
-    if constexpr (PHASE != 0)
+    // ---------------- phase 1: wave owns query tile qt -> dQ             (As = K image, Bs = V image)
+    if constexpr (PHASE == 1)
     for (int qt = wave; qt < nqt; qt += NW) {
         f32x16 dQt[DT];
 #pragma unroll
@@ -476,26 +522,50 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
 #pragma unroll
             for (int r = 0; r < 16; ++r) dQt[i][r] = 0.f;
         const int q = qt * 32 + l31;
-        const float lq = lse2[q], dq_ = dlt[q];
         bf16x8v qfr[KS], dofr[KS];
+        float dpart = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            qfr[ks] = rowfrag(Qs, (qt * 32 + l31) * RS + ks * 32 + kh * 16);
-            dofr[ks] = rowfrag(dOs, (qt * 32 + l31) * RS + ks * 32 + kh * 16);
-        }
-        for (int kt = 0; kt < nkt; ++kt) {
-            f32x16 s, dpv;
+            uint4 qv = make_uint4(0u, 0u, 0u, 0u), g = qv, o = qv;
+            if (q < Lq) {
+                qv = *reinterpret_cast<const uint4*>(qg + (size_t)q * d.ldq + ks * 16 + 8 * kh);
+                g = *reinterpret_cast<const uint4*>(dog + (size_t)q * d.lddo + ks * 16 + 8 * kh);
+                o = *reinterpret_cast<const uint4*>(og + (size_t)q * d.ldo + ks * 16 + 8 * kh);
+            }
+            qfr[ks] = __builtin_bit_cast(bf16x8v, qv);
+            const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, ow[4] = {o.x, o.y, o.z, o.w};
+            const uint64_t base = ((uint64_t)b * Lq + (uint64_t)q) * (uint64_t)(d.heads * DH) + (uint64_t)(h * DH + ks * 16 + 8 * kh);
+            float gd[8];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dpv[r] = 0.f; }
+            for (int j = 0; j < 4; ++j) {
+                const float g0 = __uint_as_float(gw[j] << 16), g1 = __uint_as_float(gw[j] & 0xffff0000u);
+                const float o0 = __uint_as_float(ow[j] << 16), o1 = __uint_as_float(ow[j] & 0xffff0000u);
+                dpart += g0 * o0 + g1 * o1;
+                gd[2 * j] = dout.apply(g0, base + 2 * j);
+                gd[2 * j + 1] = dout.apply(g1, base + 2 * j + 1);
+            }
+            dofr[ks] = pack8(gd);
+        }
+        const float dq_ = dpart + __shfl_xor(dpart, 32);                 // delta[q]: the two half-waves hold the two halves of d
+        const float lq = (q < Lq) ? d.lse[(size_t)blockIdx.x * Lq + q] * LOG2E : 0.f;
+        f32x16 s_next, dp_next;
+        auto scoresB = [&](int kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s_next[r] = 0.f; dp_next[r] = 0.f; }
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const int off = (kt * 32 + l31) * RS + ks * 32 + kh * 16;
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Ks, off), qfr[ks], s, 0, 0, 0);        // S^T[key][q]
-                dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Vs, off), dofr[ks], dpv, 0, 0, 0);   // dP^T[key][q]
+                s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(As, off), qfr[ks], s_next, 0, 0, 0);        // S^T[key][q]
+                dp_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Bs, off), dofr[ks], dp_next, 0, 0, 0);    // dP^T[key][q]
             }
+        };
+        scoresB(0);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const f32x16 s = s_next, dpv = dp_next;
+            if (kt + 1 < nkt) scoresB(kt + 1);
             float ds[16];
             const bool full = nomask && (kt * 32 + 32 <= Lk) && (qt * 32 + 32 <= Lq);
-            const uint64_t pair_base = (pbase + (uint64_t)q) * (uint64_t)LkH;
+            const uint32_t pair_base = (pbase + (uint32_t)q) * (uint32_t)LkH;
             if (full) {
                 if (dp.on) bwdB_tile<true, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
                 else bwdB_tile<true, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
@@ -508,40 +578,30 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
             for (int i = 0; i < DT; ++i)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
-                    dQt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Ks, RS, kt * 32 + 16 * s2, i * 32, lane), sf[s2], dQt[i], 0, 0, 0);
+                    dQt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(As, RS, kt * 32 + 16 * s2, i * 32, lane), sf[s2], dQt[i], 0, 0, 0);
         }
-        uint16_t* outg = reinterpret_cast<uint16_t*>(d.dq) + (size_t)b * Lq * d.lddq + h * DH;
-#pragma unroll
-        for (int i = 0; i < DT; ++i) {
-            wave_lds_fence();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[l31 * SLD + mrow(r, kh)] = dQt[i][r];
-            wave_lds_fence();
-            for (int idx = lane; idx < 32 * CW; idx += 64) {
-                const int row = idx / CW, c = idx % CW;
-                if (qt * 32 + row < Lq) {
-                    const float* p = sc + row * SLD + 4 * c;
-                    io<uint16_t>::st4(outg + (size_t)(qt * 32 + row) * d.lddq + i * 32 + 4 * c, make_float4(p[0], p[1], p[2], p[3]));
-                }
-            }
-        }
+        store_tile_T<DH, DT>(sct, RS, dQt, reinterpret_cast<uint16_t*>(d.dq) + (size_t)b * Lq * d.lddq + h * DH, d.lddq, qt * 32, Lq, lane);
     }
 }
 
-// waves per workgroup of the backward kernel: 8 (two per SIMD, 256-register budget) or 4 (one per SIMD, 512)
-int bwd_waves() {
-    static int w = [] { const char* e = getenv("MMFM_ATTN_BWD_WAVES"); return (e && atoi(e) == 4) ? 4 : 8; }();
-    return w;
+// waves per workgroup (MMFM_ATTN_FWD_WAVES / MMFM_ATTN_BWD_WAVES = 4 or 8).  Smaller workgroups let more of them
+// co-reside on a CU, which is what hides each workgroup's dispatch + load prologue.
+int env_waves(const char* name, int dflt) {
+    const char* e = getenv(name);
+    const int v = e ? atoi(e) : dflt;
+    return (v == 4 || v == 8) ? v : dflt;
 }
+int fwd_waves() { static int w = env_waves("MMFM_ATTN_FWD_WAVES", 4); return w; }
+int bwd_waves() { static int w = env_waves("MMFM_ATTN_BWD_WAVES", 4); return w; }
 
-constexpr int FWD_WAVES = 8;
-size_t fwd_lds(int Lq, int Lk, int dh) {
+size_t fwd_lds(int Lq, int Lk, int dh, int nw) {
     const int DT = (dh + 31) / 32, LkP = (Lk + 31) & ~31;
-    return (size_t)LkP * (dh * 2 + 16) + (size_t)LkP * DT * 64 + (size_t)FWD_WAVES * 32 * (DT * 32 + 1) * 4 + LkP + std::max(Lq, Lk) + 64;
+    return (size_t)LkP * (dh * 2 + 16) + (size_t)LkP * DT * 64 + (size_t)nw * 32 * (DT * 32 + 1) * 4 + LkP + std::max(Lq, Lk) + 64;
 }
-size_t bwd_lds(int Lq, int Lk, int dh, int nw) {
-    const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31;
-    return (size_t)(2 * LqP + 2 * LkP) * (dh * 2 + 16) + (size_t)2 * LqP * 4 + (size_t)nw * 32 * 33 * 4 + LkP + std::max(Lq, Lk) + 64;
+size_t bwd_lds(int Lq, int Lk, int dh, int nw, int phase) {
+    const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31, RS = dh * 2 + 16;
+    const size_t images = (size_t)2 * (phase == 0 ? LqP : LkP) * RS;
+    return images + (phase == 0 ? (size_t)2 * LqP * 4 : 0) + (size_t)nw * 32 * RS + LkP + std::max(Lq, Lk) + 64;
 }
 
 int opt_in_lds(const void* kern, size_t bytes) {
@@ -566,35 +626,40 @@ int mmfm_attn_bf16_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st
                     (uintptr_t)d.k % 16 == 0 && (uintptr_t)d.v % 16 == 0 && (uintptr_t)d.o % 16 == 0;
     if (!al) return -1000;
     if (backward) {
-        const bool alb = d.lddo % 8 == 0 && d.lddq % 4 == 0 && d.lddk % 4 == 0 && d.lddv % 4 == 0 && (uintptr_t)d.d_o % 16 == 0;
+        const bool alb = d.lddo % 8 == 0 && d.lddq % 8 == 0 && d.lddk % 8 == 0 && d.lddv % 8 == 0 && (uintptr_t)d.d_o % 16 == 0 &&
+                         (uintptr_t)d.dq % 16 == 0 && (uintptr_t)d.dk % 16 == 0 && (uintptr_t)d.dv % 16 == 0;
         if (!alb) return -1000;
         const int nw = bwd_waves();
-        const size_t lds = bwd_lds(d.Lq, d.Lk, d.dh, nw);
-        if (lds > 160 * 1024) return -1000;
+        const size_t lds0 = bwd_lds(d.Lq, d.Lk, d.dh, nw, 0), lds1 = bwd_lds(d.Lq, d.Lk, d.dh, nw, 1);
+        if (lds0 > 160 * 1024 || lds1 > 160 * 1024) return -1000;
 #define BWD1(DHV, NWV, PH)                                                                                        \
         {                                                                                                         \
             auto kern = attn_bwd_bf16_kernel<DHV, NWV, PH>;                                                       \
+            const size_t lds = PH == 0 ? lds0 : lds1;                                                             \
             if (int rc = opt_in_lds(reinterpret_cast<const void*>(kern), lds)) return rc;                         \
             hipLaunchKernelGGL(kern, dim3(d.B * d.heads), dim3(NWV * 64), lds, st, d);                            \
         }
 #define BWD(DHV)                                                                                                  \
-        if (nw == 8) { BWD1(DHV, 8, 0) BWD1(DHV, 8, 1) } else { BWD1(DHV, 4, 2) }
+        if (nw == 8) { BWD1(DHV, 8, 0) BWD1(DHV, 8, 1) } else { BWD1(DHV, 4, 0) BWD1(DHV, 4, 1) }
         if (d.dh == 16) { BWD(16) } else if (d.dh == 32) { BWD(32) } else { BWD(64) }
 #undef BWD
 #undef BWD1
         MMFM_LAUNCH_CHECK("mmfm_attn_bwd(bf16)");
         return 0;
     }
-    const size_t lds = fwd_lds(d.Lq, d.Lk, d.dh);
+    const int nw = fwd_waves();
+    const size_t lds = fwd_lds(d.Lq, d.Lk, d.dh, nw);
     if (lds > 160 * 1024) return -1000;
-#define FWD(DHV)                                                                                                  \
+#define FWD1(DHV, NWV)                                                                                            \
     {                                                                                                             \
-        auto kern = attn_fwd_bf16_kernel<DHV, FWD_WAVES>;                                                         \
+        auto kern = attn_fwd_bf16_kernel<DHV, NWV>;                                                               \
         if (int rc = opt_in_lds(reinterpret_cast<const void*>(kern), lds)) return rc;                             \
-        hipLaunchKernelGGL(kern, dim3(d.B * d.heads), dim3(FWD_WAVES * 64), lds, st, d);                          \
+        hipLaunchKernelGGL(kern, dim3(d.B * d.heads), dim3(NWV * 64), lds, st, d);                                \
     }
-    if (d.dh == 16) FWD(16) else if (d.dh == 32) FWD(32) else FWD(64)
+#define FWD(DHV) if (nw == 8) FWD1(DHV, 8) else FWD1(DHV, 4)
+    if (d.dh == 16) { FWD(16) } else if (d.dh == 32) { FWD(32) } else { FWD(64) }
 #undef FWD
+#undef FWD1
     MMFM_LAUNCH_CHECK("mmfm_attn_fwd(bf16)");
     return 0;
 }
