@@ -34,8 +34,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=int(os.environ.get("MMFM_BENCH_BATCH", "256")), help="samples per GPU per step")
-    ap.add_argument("--dtype", default=os.environ.get("MMFM_DTYPE", "fp32"), choices=["fp32", "bf16"])
+    ap.add_argument("--batch", type=int, default=int(os.environ.get("MMFM_BENCH_BATCH", "1024")), help="samples per GPU per step")
+    ap.add_argument("--dtype", default=os.environ.get("MMFM_DTYPE", "bf16"), choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=4)
@@ -73,20 +73,23 @@ def kernel_profile(engine, plan, reps=3):
         ev1.record()
         torch.cuda.synchronize()
         ms = ev0.elapsed_time(ev1) / reps
-        name, flops = fn.__name__, 0.0
+        name, flops, sub = fn.__name__, 0.0, None
         if name == "mmfm_gemm":
             d = keep[0]
             flops = 2.0 * d.M * d.N * d.K
-            name = f"mmfm_gemm[{'T' if not d.a_kcontig else 'N'}{'T' if d.b_kcontig else 'N'}]"
+            sub = "x.W^T" if (d.a_kcontig and d.b_kcontig) else ("dY.W" if d.a_kcontig else "dY^T.X")
         elif name in ("mmfm_attn_fwd", "mmfm_attn_bwd"):
             d = keep[0]
             flops = (4.0 if name.endswith("fwd") else 10.0) * d.B * d.heads * d.Lq * d.Lk * d.dh
-        rows.append((name, ms, flops))
-    agg = {}
-    for name, ms, fl in rows:
+        rows.append((name, ms, flops, sub))
+    agg, subs = {}, {}
+    for name, ms, fl, sub in rows:
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1; a[1] += ms; a[2] += fl
-    return agg
+        if sub:
+            b = subs.setdefault(sub, [0, 0.0, 0.0])
+            b[0] += 1; b[1] += ms; b[2] += fl
+    return agg, subs
 
 
 def cpu_baseline(steps, B=16):
@@ -224,10 +227,11 @@ def main():
         log(f"{ms:.2f} ms/step, {value:.1f} samples/s")
         if not a.no_kernel_profile:
             log("per-kernel HIP-event profile")
-            agg = kernel_profile(eng, eng._last)
+            agg, subs = kernel_profile(eng, eng._last)
             tot = sum(v[1] for v in agg.values())
             top = sorted(agg.items(), key=lambda kv: -kv[1][1])
             res["kernel_breakdown_ms"] = {k: round(v[1], 3) for k, v in top[:8]}
+            res["gemm_layouts"] = {k: dict(launches=v[0], ms=round(v[1], 3), tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1)) for k, v in subs.items()}
             res["kernel_time_sum_ms"] = round(tot, 3)
             mf = [(k, v) for k, v in top if v[2] > 0]
             k, v = mf[0]

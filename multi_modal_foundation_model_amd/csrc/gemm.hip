@@ -366,7 +366,8 @@ extern "C" int mmfm_reduce_slabs(float* dst, const float* src_c, int64_t n, int 
     return 0;
 }
 
-static int colsum_splits(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(256, R / 64)); }
+// short inputs (launch-bound regime): <= 15 partials so that the reduction is ONE small launch
+static int colsum_splits(int64_t R) { return R <= 8192 ? (int)std::max<int64_t>(1, std::min<int64_t>(15, R / 256)) : (int)std::min<int64_t>(256, R / 64); }
 
 extern "C" int64_t mmfm_colsum_workspace(int64_t R, int N) { return (int64_t)colsum_splits(R) * N * sizeof(float); }
 

@@ -12,13 +12,19 @@
 //      (hardware 4x16 transpose); the XOR spreads the four k-rows of a read over the four 64-B quarters
 //      of the bank row -> conflict-free.  Global loads stay 16 B/lane along the contiguous axis.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int KC_LD = 72;                   // bf16 elements per LDS row of a KC image
-constexpr int TILE_BYTES = 128 * KC_LD * 2; // 18432 (>= the RC image's 64*256 = 16384)
+constexpr int BM = 128, BN = 128;
 constexpr int NTHREADS = 256;
+// BK (k-tile depth) is a template parameter: 64 (36 KB LDS, up to 4 workgroups/CU) or 128 (70 KB, 2/CU, half the
+// load-latency rounds for the K = 256 shapes).  KC image rows are BK + 8 elements: 144 B / 272 B, both conflict-free.
+template <int BK> struct Geo {
+    static constexpr int KC_LD = BK + 8;
+    static constexpr int TILE_BYTES = 128 * KC_LD * 2;     // >= RC image BK * 256
+    static constexpr int NP = BK / 16;                     // uint4 per thread per operand tile
+};
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -41,36 +47,38 @@ __device__ __forceinline__ uint4 load8(const uint16_t* __restrict__ src, int nva
     return v;
 }
 
-template <bool RC>
-__device__ __forceinline__ void g2r(uint4 (&r)[4], const uint16_t* __restrict__ base, int ld, int row0, int k0, int rows, int kend,
+template <bool RC, int BK>
+__device__ __forceinline__ void g2r(uint4 (&r)[BK / 16], const uint16_t* __restrict__ base, int ld, int row0, int k0, int rows, int kend,
                                     int align, int t) {
-    if (!RC) {          // reduction contiguous: 8 lanes x 16 B = one 128-B row segment
-        const int kq = t & 7, r0 = t >> 3, k = k0 + 8 * kq;
+    constexpr int NP = BK / 16, LPR = BK / 8, RPP = 256 / LPR;      // lanes per row, rows per pass
+    if (!RC) {          // reduction contiguous: LPR lanes x 16 B = one BK*2-byte row segment
+        const int kq = t % LPR, r0 = t / LPR, k = k0 + 8 * kq;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int row = row0 + r0 + 32 * p;
+        for (int p = 0; p < NP; ++p) {
+            const int row = row0 + r0 + RPP * p;
             r[p] = (row < rows) ? load8(base + (size_t)row * ld + k, kend - k, align) : make_uint4(0u, 0u, 0u, 0u);
         }
     } else {            // row contiguous: 16 lanes x 16 B = 256 B of one k-row
         const int cq = t & 15, kk0 = t >> 4, col = row0 + 8 * cq;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int k = k0 + kk0 + 16 * p;
             r[p] = (k < kend) ? load8(base + (size_t)k * ld + col, rows - col, align) : make_uint4(0u, 0u, 0u, 0u);
         }
     }
 }
 
-template <bool RC>
-__device__ __forceinline__ void r2s(char* __restrict__ S, const uint4 (&r)[4], int t) {
+template <bool RC, int BK>
+__device__ __forceinline__ void r2s(char* __restrict__ S, const uint4 (&r)[BK / 16], int t) {
+    constexpr int NP = BK / 16, LPR = BK / 8, RPP = 256 / LPR, KC_LD = Geo<BK>::KC_LD;
     if (!RC) {
-        const int kq = t & 7, r0 = t >> 3;
+        const int kq = t % LPR, r0 = t / LPR;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<uint4*>(S + (r0 + 32 * p) * (KC_LD * 2) + kq * 16) = r[p];
+        for (int p = 0; p < NP; ++p) *reinterpret_cast<uint4*>(S + (r0 + RPP * p) * (KC_LD * 2) + kq * 16) = r[p];
     } else {
         const int cq = t & 15, kk0 = t >> 4;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
+        for (int p = 0; p < NP; ++p) {
             const int kk = kk0 + 16 * p;
             *reinterpret_cast<uint4*>(S + kk * 256 + ((cq * 16) ^ ((kk & 3) << 6))) = r[p];
         }
@@ -79,11 +87,11 @@ __device__ __forceinline__ void r2s(char* __restrict__ S, const uint4 (&r)[4], i
 
 // MFMA operand for rows [rowbase, rowbase+32) and k in [16*ks, 16*ks+16): lane (r = lane%32, h = lane/32)
 // holds row rowbase + r, k = 16*ks + 8*h + 0..7
-template <bool RC>
+template <bool RC, int BK>
 __device__ __forceinline__ bf16x8v frag(const char* __restrict__ S, int rowbase, int ks, int lane) {
     if (!RC) {
         const int r = lane & 31, h = lane >> 5;
-        const uint4 v = *reinterpret_cast<const uint4*>(S + (rowbase + r) * (KC_LD * 2) + ks * 32 + h * 16);
+        const uint4 v = *reinterpret_cast<const uint4*>(S + (rowbase + r) * (Geo<BK>::KC_LD * 2) + ks * 32 + h * 16);
         return __builtin_bit_cast(bf16x8v, v);
     } else {
         // ds_read_b64_tr_b16: per 16-lane group a 4(k) x 16(row) block; lane 4q+p supplies row q's address at
@@ -137,8 +145,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <bool ARC, bool BRC, typename TO>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const mmfm_gemm_desc d, const int alignA, const int alignB, const int vec_epi) {
+template <bool ARC, bool BRC, typename TO, int BK>
+__global__ __launch_bounds__(NTHREADS, BK == 64 ? 3 : 2) void gemm_bf16_kernel(const mmfm_gemm_desc d, const int alignA, const int alignB,
+                                                                              const int vec_epi) {
+    constexpr int TILE_BYTES = Geo<BK>::TILE_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
     char* As = smem;
     char* Bs = smem + TILE_BYTES;
@@ -161,22 +171,22 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const mmfm_gemm_des
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    uint4 ra[4], rb[4];
-    g2r<ARC>(ra, A, d.lda, m0, kbeg, d.M, kend, alignA, t);
-    g2r<BRC>(rb, B, d.ldb, n0, kbeg, d.N, kend, alignB, t);
+    uint4 ra[BK / 16], rb[BK / 16];
+    g2r<ARC, BK>(ra, A, d.lda, m0, kbeg, d.M, kend, alignA, t);
+    g2r<BRC, BK>(rb, B, d.ldb, n0, kbeg, d.N, kend, alignB, t);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         __syncthreads();
-        r2s<ARC>(As, ra, t);
-        r2s<BRC>(Bs, rb, t);
+        r2s<ARC, BK>(As, ra, t);
+        r2s<BRC, BK>(Bs, rb, t);
         __syncthreads();
         if (k0 + BK < kend) {
-            g2r<ARC>(ra, A, d.lda, m0, k0 + BK, d.M, kend, alignA, t);
-            g2r<BRC>(rb, B, d.ldb, n0, k0 + BK, d.N, kend, alignB, t);
+            g2r<ARC, BK>(ra, A, d.lda, m0, k0 + BK, d.M, kend, alignA, t);
+            g2r<BRC, BK>(rb, B, d.ldb, n0, k0 + BK, d.N, kend, alignB, t);
         }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
-            const bf16x8v a0 = frag<ARC>(As, wm * 64, ks, lane), a1 = frag<ARC>(As, wm * 64 + 32, ks, lane);
-            const bf16x8v b0 = frag<BRC>(Bs, wn * 64, ks, lane), b1 = frag<BRC>(Bs, wn * 64 + 32, ks, lane);
+            const bf16x8v a0 = frag<ARC, BK>(As, wm * 64, ks, lane), a1 = frag<ARC, BK>(As, wm * 64 + 32, ks, lane);
+            const bf16x8v b0 = frag<BRC, BK>(Bs, wn * 64, ks, lane), b1 = frag<BRC, BK>(Bs, wn * 64 + 32, ks, lane);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
@@ -295,7 +305,14 @@ int align_of(const void* p, int ld) {
 
 int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     const mmfm_gemm_desc d = *dp;
-    MMFM_REQUIRE(d.splits == 1 || d.kchunk % BK == 0, "mmfm_gemm(bf16): kchunk %d must be a multiple of %d", d.kchunk, BK);
+    MMFM_REQUIRE(d.splits == 1 || d.kchunk % 64 == 0, "mmfm_gemm(bf16): kchunk %d must be a multiple of 64", d.kchunk);
+    static const int bk_env = [] { const char* e = getenv("MMFM_GEMM_BK"); return e ? atoi(e) : 0; }();
+    // deeper k-tiles when the reduction is short (K = 256/512 block GEMMs): fewer serialized load-latency rounds
+    const int kspan = d.splits > 1 ? d.kchunk : d.K;
+    // measured on MI355X (scripts/gemm_bench.py): BK = 128 is 0-15 % SLOWER than BK = 64 at 3 workgroups/CU for the
+    // K = 256/512 shapes (the kernel is bound by ds_write + L1 + MFMA issue, not by load-latency rounds) -> default 64
+    (void)kspan;
+    const int BKsel = bk_env == 128 ? 128 : 64;
     const int tiles = cdiv(d.M, BM) * cdiv(d.N, BN);
     const int aA = align_of(d.A, d.lda), aB = align_of(d.B, d.ldb);
     dim3 grid(tiles, d.splits), block(NTHREADS);
@@ -304,13 +321,15 @@ int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     auto al16 = [](const void* p) { return p == nullptr || (uintptr_t)p % 16 == 0; };
     const int vec = (d.N % 8 == 0) && (d.ldc % 8 == 0) && al16(d.C) && al16(d.pre_out) && al16(d.gradmul_pre) && al16(d.bias) &&
                     (!d.residual || (d.ldr % 8 == 0 && al16(d.residual))) && (!d.splits || d.splits == 1 || d.slab_stride % 4 == 0);
-#define LAUNCH(ARC, BRC)                                                                                          \
-    if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float>), grid, block, 0, st, d, aA, aB, vec);       \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t>), grid, block, 0, st, d, aA, aB, vec);
+#define LAUNCH2(ARC, BRC, BKV)                                                                                    \
+    if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float, BKV>), grid, block, 0, st, d, aA, aB, vec);  \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t, BKV>), grid, block, 0, st, d, aA, aB, vec);
+#define LAUNCH(ARC, BRC) if (BKsel == 128) { LAUNCH2(ARC, BRC, 128) } else { LAUNCH2(ARC, BRC, 64) }
     if (d.a_kcontig && d.b_kcontig) { LAUNCH(false, false) }
     else if (d.a_kcontig && !d.b_kcontig) { LAUNCH(false, true) }
     else { LAUNCH(true, true) }
 #undef LAUNCH
+#undef LAUNCH2
     MMFM_LAUNCH_CHECK("mmfm_gemm(bf16)");
     return 0;
 }

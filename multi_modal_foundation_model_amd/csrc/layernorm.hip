@@ -208,6 +208,8 @@ extern "C" int mmfm_layernorm_bwd(int dtype, const void* dy, const void* x, cons
         return mmfm_set_error(-1, "mmfm_layernorm_bwd: bad dtype %d", dtype);
     MMFM_LAUNCH_CHECK("mmfm_layernorm_bwd");
     // per-block partials [nblk][2][H] -> dgamma, dbeta (two tall-skinny slab reductions)
+    if (dbeta == dgamma + H)     // adjacent in the flat gradient buffer (the engine's layout): one reduction over [2H]
+        return mmfm_reduce_slabs(dgamma, (const float*)workspace, 2 * (int64_t)H, nblk, 2 * (int64_t)H, accumulate, stream);
     if (int rc = mmfm_reduce_slabs(dgamma, (const float*)workspace, H, nblk, 2 * (int64_t)H, accumulate, stream)) return rc;
     return mmfm_reduce_slabs(dbeta, (const float*)workspace + H, H, nblk, 2 * (int64_t)H, accumulate, stream);
 }

@@ -270,7 +270,10 @@ class Engine:
         """Split-K factor for a dW GEMM ([M,N] output, reduction over R tokens): just enough splits to put
         ~2 workgroups on every CU (the slab reduction costs S x M x N x 4 bytes of traffic, so no more)."""
         tiles = -(-M // 128) * -(-N // 128)
-        S = max(1, min(R // 512, -(-512 // tiles)))
+        if R <= 8192:                     # launch-bound regime (reference batch 16 -> R = 3200): <= 15 slabs = one-stage reduce
+            S = max(1, min(R // 256, 15))
+        else:
+            S = max(1, min(R // 512, -(-512 // tiles)))
         kchunk = _align(-(-R // S), 64)          # multiple of both kernels' BK (32 fp32, 64 bf16)
         return -(-R // kchunk), kchunk
 
