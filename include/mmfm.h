@@ -165,6 +165,16 @@ int mmfm_stitch_bwd(int dtype, const void* dx, const void* dextra, const int64_t
                     int B, int T, int L, int m, int H, int max_F,
                     void* workspace, int64_t workspace_bytes, mmfm_stream stream);
 
+/* ---------------------------------------------------------------------------------- loader collate
+ * BaseDataset._preprocess_ibl_data + get_binned_spikes_from_sparse (loader/base.py:304-450,
+ * utils/dataset_utils.py:38-43), pad_to_right path: B trials given as concatenated CSR pieces
+ * (uint8 counts, int32 column indices, int64 row pointers) -> dense spikes [B][max_T][max_N] fp32,
+ * rows/columns beyond a trial's (T_b, N_b) = pad_value, longer trials truncated; time_mask [B][max_T]
+ * and space_mask [B][max_N] int64 (1 = real data).  Duplicate (row, col) entries add up. */
+int mmfm_collate_csr(int B, int max_T, int max_N, float pad_value, const uint8_t* data, const int32_t* indices,
+                     const int64_t* indptr, const int64_t* indptr_off, const int64_t* nnz_off, const int32_t* T_b,
+                     const int32_t* N_b, float* out, int64_t* time_mask, int64_t* space_mask, mmfm_stream stream);
+
 /* ---------------------------------------------------------------------------------- masked loss
  * mm.py:79-82,217-239.  kind 0: PoissonNLL(log_input) exp(p) - t*p;  kind 1: MSE (p-t)^2.
  * pred [R][N] (dtype), target [R][N] fp32, rowmask u8 [R] (element (b,t) at rowmask[b*mask_ld + t]).

@@ -107,6 +107,44 @@ __global__ void stitch_bwd_kernel(const T* __restrict__ dx, const T* __restrict_
     out[(size_t)max_F * H + col] = macc;
 }
 
+// Loader collate (loader/base.py:304-450, utils/dataset_utils.py:38-43): CSR (uint8 counts) ->
+// dense [B][max_T][max_N] fp32, truncated / right-padded with pad_value, plus the two attention masks.
+// One wavefront per (trial, time bin): the lanes fill the row (coalesced), then scatter the row's non-zeros with
+// float atomic adds (duplicate (row, col) entries of a CSR add up, like scipy's toarray()).
+struct CollateArgs {
+    const uint8_t* data;
+    const int32_t* indices;
+    const int64_t* indptr;        // concatenated per-trial indptr arrays (T_b + 1 entries each)
+    const int64_t* indptr_off;    // [B] offset of trial b's indptr
+    const int64_t* nnz_off;       // [B] offset of trial b's data/indices
+    const int32_t* T_b;
+    const int32_t* N_b;
+};
+__global__ __launch_bounds__(256) void collate_csr_kernel(CollateArgs a, int B, int max_T, int max_N, float pad, float* __restrict__ out,
+                                                          int64_t* __restrict__ tmask, int64_t* __restrict__ smask) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < (int64_t)B * max_T; row += (int64_t)gridDim.x * 4) {
+        const int b = (int)(row / max_T), t = (int)(row % max_T);
+        const int Tb = a.T_b[b], Nb = a.N_b[b];
+        const bool live = t < Tb;                       // rows past the trial's length are padding
+        const int nvalid = min(Nb, max_N);
+        float* o = out + row * max_N;
+        for (int n = lane; n < max_N; n += 64) o[n] = (live && n < nvalid) ? 0.f : pad;
+        if (lane == 0) tmask[row] = live ? 1 : 0;
+        if (t == 0)
+            for (int n = lane; n < max_N; n += 64) smask[(size_t)b * max_N + n] = n < nvalid ? 1 : 0;
+        if (!live) continue;
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        const int64_t* ip = a.indptr + a.indptr_off[b];
+        const int64_t z0 = ip[t], z1 = ip[t + 1], base = a.nnz_off[b];
+        for (int64_t z = z0 + lane; z < z1; z += 64) {
+            const int col = a.indices[base + z];
+            if (col >= 0 && col < nvalid) atomicAdd(o + col, (float)a.data[base + z]);
+        }
+    }
+}
+
 int pick_cw(int H, int max_F) {
     for (int cw : {256, 128, 64, 32, 16, 8, 4})
         if (H % cw == 0 && (size_t)max_F * cw * 4 <= 60 * 1024) return cw;
@@ -138,6 +176,19 @@ extern "C" int mmfm_mask_prep(int B, int T, int M, const int64_t* const* mask_sr
     hipLaunchKernelGGL(mask_prep_kernel, dim3((int)std::min<int64_t>(256, (n + 255) / 256)), dim3(256), 0, st, src, attn, B, T, M,
                        tokmask, keypad, keep0, mod_id, (unsigned long long*)count);
     MMFM_LAUNCH_CHECK("mmfm_mask_prep");
+    return 0;
+}
+
+extern "C" int mmfm_collate_csr(int B, int max_T, int max_N, float pad_value, const uint8_t* data, const int32_t* indices,
+                                const int64_t* indptr, const int64_t* indptr_off, const int64_t* nnz_off, const int32_t* T_b,
+                                const int32_t* N_b, float* out, int64_t* time_mask, int64_t* space_mask, mmfm_stream stream) {
+    MMFM_REQUIRE(B > 0 && max_T > 0 && max_N > 0, "mmfm_collate_csr: bad shape");
+    MMFM_REQUIRE(indptr && indptr_off && nnz_off && T_b && N_b && out && time_mask && space_mask, "mmfm_collate_csr: null pointer");
+    CollateArgs a{data, indices, indptr, indptr_off, nnz_off, T_b, N_b};
+    const int64_t rows = (int64_t)B * max_T;
+    hipLaunchKernelGGL(collate_csr_kernel, dim3((int)std::min<int64_t>(4096, (rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a, B, max_T,
+                       max_N, pad_value, out, time_mask, space_mask);
+    MMFM_LAUNCH_CHECK("mmfm_collate_csr");
     return 0;
 }
 

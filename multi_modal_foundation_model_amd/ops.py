@@ -151,3 +151,8 @@ def rng_seed(state, seed, plan=None):
 
 def rng_advance(state, plan=None):
     _emit(plan, L.lib().mmfm_rng_advance, (P(state),))
+
+
+def collate_csr(B, max_T, max_N, pad_value, data, indices, indptr, indptr_off, nnz_off, T_b, N_b, out, tmask, smask, plan=None):
+    _emit(plan, L.lib().mmfm_collate_csr, (B, max_T, max_N, float(pad_value), P(data), P(indices), P(indptr), P(indptr_off), P(nnz_off),
+                                           P(T_b), P(N_b), P(out), P(tmask), P(smask)))

@@ -470,13 +470,48 @@ def fx_trainer_io():
         eval_trial_avg_r2=float(ev["eval_trial_avg_r2"])))
 
 
+def fx_loader_collate():
+    """The reference's BaseDataset.__getitem__ (loader/base.py:304-450) on ragged synthetic CSR trials."""
+    from scipy.sparse import csr_array
+    import datasets
+    if not hasattr(datasets, "list_datasets"):      # removed from the installed `datasets` release; the reference's
+        datasets.list_datasets = lambda *a, **k: []  # utils/dataset_utils.py imports the name at module load (unused here)
+    from loader.base import BaseDataset
+    rng = np.random.default_rng(5)
+    max_T, max_N, pad = 10, 14, -1.0
+    trials, arrs, meta = [], {}, []
+    for i, (T_i, N_i) in enumerate([(10, 14), (7, 14), (10, 9), (6, 5), (13, 14), (10, 17), (12, 20), (2, 3)]):
+        dense = (rng.random((T_i, N_i)) < 0.25) * rng.integers(1, 4, (T_i, N_i))
+        sp = csr_array(dense.astype(np.uint8))
+        d = dict(spikes_sparse_data=sp.data.tolist(), spikes_sparse_indices=sp.indices.tolist(),
+                 spikes_sparse_indptr=sp.indptr.tolist(), spikes_sparse_shape=list(sp.shape),
+                 choice=float(i % 2), block=0.2 * i, reward=float((i + 1) % 2), eid=f"eid{i}",
+                 cluster_depths=rng.random(N_i).tolist(), cluster_regions=[f"R{j % 3}" for j in range(N_i)])
+        d["wheel-speed"] = rng.standard_normal(T_i).tolist()
+        d["whisker-motion-energy"] = rng.standard_normal(T_i).tolist()
+        trials.append(d)
+    ds = BaseDataset(dataset=trials, target=["wheel-speed", "whisker-motion-energy"], pad_value=pad, max_time_length=max_T,
+                     max_space_length=max_N, pad_to_right=True, load_meta=True, dataset_name="ibl")
+    for i, d in enumerate(trials):
+        out = ds[i]
+        for k in ("spikes_sparse_data", "spikes_sparse_indices", "spikes_sparse_indptr", "spikes_sparse_shape", "wheel-speed",
+                  "whisker-motion-energy", "cluster_depths"):
+            arrs[f"t{i}/in/{k}"] = np.asarray(d[k])
+        for k in ("spikes_data", "time_attn_mask", "space_attn_mask", "spikes_timestamps", "spikes_spacestamps", "target",
+                  "neuron_depths", "choice", "block", "reward"):
+            arrs[f"t{i}/out/{k}"] = np.asarray(out[k])
+        meta.append(dict(eid=out["eid"], regions_in=d["cluster_regions"], regions_out=[str(x) for x in out["neuron_regions"]]))
+    arrs["meta"] = np.frombuffer(json.dumps(dict(max_T=max_T, max_N=max_N, pad=pad, trials=meta)).encode(), dtype=np.uint8)
+    save_npz("loader_collate.npz", **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in [("init_order", fx_init_order), ("tiny_fwd_bwd", fx_tiny_fwd_bwd),
                      ("default_scalars", fx_default_scalars), ("masker_bits", fx_masker_bits),
                      ("mask_index_ops", fx_mask_index_ops), ("sched_adamw", fx_sched_adamw),
-                     ("loss_curve", fx_loss_curve), ("trainer_io", fx_trainer_io)]:
+                     ("loss_curve", fx_loss_curve), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate)]:
         if only and name not in only:
             continue
         print(f"[{name}]")
