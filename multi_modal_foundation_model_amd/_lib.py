@@ -15,7 +15,7 @@ import re
 import torch  # noqa: F401  (load order matters)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmmfm_hip.so")
+LIB_PATH = os.environ.get("MMFM_LIB") or os.path.join(_HERE, "libmmfm_hip.so")    # MMFM_LIB: A/B another build of the same library
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmfm.h")
 
 F32, BF16 = 0, 1

@@ -13,6 +13,7 @@
 //      of the bank row -> conflict-free.  Global loads stay 16 B/lane along the contiguous axis.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -145,62 +146,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-template <bool ARC, bool BRC, typename TO, int BK>
-__global__ __launch_bounds__(NTHREADS, BK == 64 ? 3 : 2) void gemm_bf16_kernel(const mmfm_gemm_desc d, const int alignA, const int alignB,
-                                                                              const int vec_epi) {
-    constexpr int TILE_BYTES = Geo<BK>::TILE_BYTES;
-    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
-    char* As = smem;
-    char* Bs = smem + TILE_BYTES;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave >> 1, wn = wave & 1, kh = lane >> 5, l31 = lane & 31;
-    const int tiles_n = (d.N + BN - 1) / BN;
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
-    const int z = blockIdx.y;
-    const int kbeg = z * d.kchunk;
-    const int kend = min(d.K, kbeg + d.kchunk);
-    const uint16_t* A = reinterpret_cast<const uint16_t*>(d.A);
-    const uint16_t* B = reinterpret_cast<const uint16_t*>(d.B);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    uint4 ra[BK / 16], rb[BK / 16];
-    g2r<ARC, BK>(ra, A, d.lda, m0, kbeg, d.M, kend, alignA, t);
-    g2r<BRC, BK>(rb, B, d.ldb, n0, kbeg, d.N, kend, alignB, t);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        __syncthreads();
-        r2s<ARC, BK>(As, ra, t);
-        r2s<BRC, BK>(Bs, rb, t);
-        __syncthreads();
-        if (k0 + BK < kend) {
-            g2r<ARC, BK>(ra, A, d.lda, m0, k0 + BK, d.M, kend, alignA, t);
-            g2r<BRC, BK>(rb, B, d.ldb, n0, k0 + BK, d.N, kend, alignB, t);
-        }
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            const bf16x8v a0 = frag<ARC, BK>(As, wm * 64, ks, lane), a1 = frag<ARC, BK>(As, wm * 64 + 32, ks, lane);
-            const bf16x8v b0 = frag<BRC, BK>(Bs, wn * 64, ks, lane), b1 = frag<BRC, BK>(Bs, wn * 64 + 32, ks, lane);
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-        }
-    }
-
+// Epilogue of one output tile (see the comment inside).  `smem` is the workgroup's operand LDS, free at this point.
+template <typename TO>
+__device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int z, int vec_epi,
+                                              int t, int wm, int wn, int kh, int l31) {
+    if ((vec_epi & 256) && acc[0][0][0] != 12345.678f) return;      // ablation hook: no epilogue (keeps the MFMAs live)
     // ---- epilogue.  Fast path (row-aligned shapes): the fp32 tile is staged through LDS half a tile at a time
     // (64 rows x 128 cols x 4 B = 32 KB, reusing the operand buffers) so that each thread owns 8 consecutive
     // columns of a row: bias/pre-activation/residual/output move as 16-B (bf16) or 2x16-B (fp32) accesses.
     const bool split = d.splits > 1;
     float* Cf = reinterpret_cast<float*>(d.C) + (split ? (size_t)z * d.slab_stride : 0);
     const Drop dr = drop_init(d.drop);
-    if (vec_epi) {
+    if (vec_epi & 1) {
         float* stage = reinterpret_cast<float*>(smem);
         constexpr int SLDW = 132;
 #pragma unroll 1
@@ -295,6 +252,87 @@ __global__ __launch_bounds__(NTHREADS, BK == 64 ? 3 : 2) void gemm_bf16_kernel(c
             }
 }
 
+// Work item = output tile x K-split; item order is XCD-aware (xcd_remap): items that share an operand panel run on one
+// XCD at about the same time.
+// fp32-output launches (split-K weight-gradient slabs, fp32 heads) are PERSISTENT: a workgroup walks items
+// w = blockIdx.x, += gridDim.x and fetches the first K-slice of the NEXT item into the staging registers before the
+// epilogue of the current one, so the slab stores overlap the next loads (measured on MI355X at B=1024: dW GEMMs 68 -> 47,
+// 130 -> 90 us).  bf16-output launches stay one item per workgroup: their epilogue LOADS (bias, residual, saved
+// pre-activation) are issued after the prefetch and vmcnt retires in order, so the epilogue would wait for the whole
+// prefetch; hoisting those loads above the prefetch costs 40 VGPRs, spills, and measured 30 % slower (194 -> 261 us).
+template <bool ARC, bool BRC, typename TO, int BK, bool PERSIST = (sizeof(TO) == 4)>
+__global__ __launch_bounds__(NTHREADS, BK == 64 ? 3 : 2) void gemm_bf16_kernel(const mmfm_gemm_desc d, const int alignA, const int alignB,
+                                                                              const int vec_epi, const int total_items) {
+    constexpr int TILE_BYTES = Geo<BK>::TILE_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE_BYTES];
+    char* As = smem;
+    char* Bs = smem + TILE_BYTES;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, kh = lane >> 5, l31 = lane & 31;
+    const int tiles_n = (d.N + BN - 1) / BN;
+    const int tiles = ((d.M + BM - 1) / BM) * tiles_n;
+    const uint16_t* A = reinterpret_cast<const uint16_t*>(d.A);
+    const uint16_t* B = reinterpret_cast<const uint16_t*>(d.B);
+
+    auto decode = [&](int w, int& m0, int& n0, int& z, int& kbeg, int& kend) {
+        const int item = xcd_remap(w, total_items);     // = z * tiles + tile: neighbours share the K range and a panel
+        z = item / tiles;
+        const int tile = item - z * tiles;
+        m0 = (tile / tiles_n) * BM;
+        n0 = (tile % tiles_n) * BN;
+        kbeg = z * d.kchunk;
+        kend = min(d.K, kbeg + d.kchunk);
+    };
+
+    int m0, n0, z, kbeg, kend;
+    int w = blockIdx.x;
+    if (w >= total_items) return;
+    decode(w, m0, n0, z, kbeg, kend);
+    uint4 ra[BK / 16], rb[BK / 16];
+    g2r<ARC, BK>(ra, A, d.lda, m0, kbeg, d.M, kend, alignA, t);
+    g2r<BRC, BK>(rb, B, d.ldb, n0, kbeg, d.N, kend, alignB, t);
+    for (;;) {
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        const int wn_ = w + gridDim.x;
+        const bool more = PERSIST && wn_ < total_items;
+        int m0n = 0, n0n = 0, zn = 0, kbegn = 0, kendn = 0;
+        if (more) decode(wn_, m0n, n0n, zn, kbegn, kendn);
+        for (int k0 = kbeg; k0 < kend; k0 += BK) {
+            __syncthreads();                   // the previous slice's MFMA reads (or the previous epilogue) are done
+            r2s<ARC, BK>(As, ra, t);
+            r2s<BRC, BK>(Bs, rb, t);
+            __syncthreads();
+            if (!(vec_epi & 512)) {
+                if (k0 + BK < kend) {          // next K-slice of this tile
+                    g2r<ARC, BK>(ra, A, d.lda, m0, k0 + BK, d.M, kend, alignA, t);
+                    g2r<BRC, BK>(rb, B, d.ldb, n0, k0 + BK, d.N, kend, alignB, t);
+                } else if (more) {             // first K-slice of the next item: in flight during this item's epilogue
+                    g2r<ARC, BK>(ra, A, d.lda, m0n, kbegn, d.M, kendn, alignA, t);
+                    g2r<BRC, BK>(rb, B, d.ldb, n0n, kbegn, d.N, kendn, alignB, t);
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const bf16x8v a0 = frag<ARC, BK>(As, wm * 64, ks, lane), a1 = frag<ARC, BK>(As, wm * 64 + 32, ks, lane);
+                const bf16x8v b0 = frag<BRC, BK>(Bs, wn * 64, ks, lane), b1 = frag<BRC, BK>(Bs, wn * 64 + 32, ks, lane);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        epilogue_tile<TO>(d, acc, smem, m0, n0, z, vec_epi, t, wm, wn, kh, l31);
+        if (!more) break;
+        w = wn_; m0 = m0n; n0 = n0n; z = zn; kbeg = kbegn; kend = kendn;
+    }
+}
+
 int align_of(const void* p, int ld) {
     if (ld % 8 == 0 && (uintptr_t)p % 16 == 0) return 8;
     if (ld % 4 == 0 && (uintptr_t)p % 8 == 0) return 4;
@@ -315,15 +353,19 @@ int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     const int BKsel = bk_env == 128 ? 128 : 64;
     const int tiles = cdiv(d.M, BM) * cdiv(d.N, BN);
     const int aA = align_of(d.A, d.lda), aB = align_of(d.B, d.ldb);
-    dim3 grid(tiles, d.splits), block(NTHREADS);
+    const int total_items = tiles * d.splits;
+    static const int wg_per_cu = [] { const char* e = getenv("MMFM_GEMM_WG_PER_CU"); const int v = e ? atoi(e) : 3; return v > 0 ? v : 3; }();
     const bool f32out = d.c_f32 || d.splits > 1;
+    dim3 grid(f32out ? std::min(total_items, 256 * wg_per_cu) : total_items), block(NTHREADS);   // persistent: 3 resident workgroups per CU
     // vector epilogue needs 16-B aligned 8-column chunks of every tensor it touches
     auto al16 = [](const void* p) { return p == nullptr || (uintptr_t)p % 16 == 0; };
     const int vec = (d.N % 8 == 0) && (d.ldc % 8 == 0) && al16(d.C) && al16(d.pre_out) && al16(d.gradmul_pre) && al16(d.bias) &&
                     (!d.residual || (d.ldr % 8 == 0 && al16(d.residual))) && (!d.splits || d.splits == 1 || d.slab_stride % 4 == 0);
+    static const int abl = [] { const char* e = getenv("MMFM_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
+    const int vecf = vec | (abl << 8);
 #define LAUNCH2(ARC, BRC, BKV)                                                                                    \
-    if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float, BKV>), grid, block, 0, st, d, aA, aB, vec);  \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t, BKV>), grid, block, 0, st, d, aA, aB, vec);
+    if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float, BKV>), grid, block, 0, st, d, aA, aB, vecf, total_items);  \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t, BKV>), grid, block, 0, st, d, aA, aB, vecf, total_items);
 #define LAUNCH(ARC, BRC) if (BKsel == 128) { LAUNCH2(ARC, BRC, 128) } else { LAUNCH2(ARC, BRC, 64) }
     if (d.a_kcontig && d.b_kcontig) { LAUNCH(false, false) }
     else if (d.a_kcontig && !d.b_kcontig) { LAUNCH(false, true) }
