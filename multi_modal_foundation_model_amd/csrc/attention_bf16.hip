@@ -625,6 +625,13 @@ int mmfm_attn_bf16_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st
     const bool al = d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.ldo % 8 == 0 && (uintptr_t)d.q % 16 == 0 &&
                     (uintptr_t)d.k % 16 == 0 && (uintptr_t)d.v % 16 == 0 && (uintptr_t)d.o % 16 == 0;
     if (!al) return -1000;
+    {   // shape decision shared by forward and backward (see use_tiled in attention.hip): all three kernels must fit
+        static const bool force_tiled = [] { const char* e = getenv("MMFM_ATTN_FORCE_TILED"); return e && atoi(e) != 0; }();
+        if (force_tiled) return -1000;
+        const int nwf = fwd_waves(), nwb = bwd_waves();
+        if (fwd_lds(d.Lq, d.Lk, d.dh, nwf) > 160 * 1024 || bwd_lds(d.Lq, d.Lk, d.dh, nwb, 0) > 160 * 1024 ||
+            bwd_lds(d.Lq, d.Lk, d.dh, nwb, 1) > 160 * 1024) return -1000;
+    }
     if (backward) {
         const bool alb = d.lddo % 8 == 0 && d.lddq % 8 == 0 && d.lddk % 8 == 0 && d.lddv % 8 == 0 && (uintptr_t)d.d_o % 16 == 0 &&
                          (uintptr_t)d.dq % 16 == 0 && (uintptr_t)d.dk % 16 == 0 && (uintptr_t)d.dv % 16 == 0;

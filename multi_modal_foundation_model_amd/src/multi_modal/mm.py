@@ -35,6 +35,20 @@ class MultiModalOutput(ModelOutput):
     mod_targets: Optional[Dict[str, torch.FloatTensor]] = None
 
 
+def _loss_kind(spec) -> int:
+    """loss_mod entry -> mmfm_masked_loss kind.  Entries are strings here; the reference's entries are
+    nn.PoissonNLLLoss(reduction="none", log_input=True) / nn.MSELoss(reduction="none") (mm.py:79-82), accepted too, so
+    `model.loss_mod['lfp'] = nn.MSELoss(reduction='none')` adds a modality exactly as it would upstream."""
+    name = (spec if isinstance(spec, str) else type(spec).__name__).lower()
+    if "poisson" in name:
+        if not isinstance(spec, str) and not getattr(spec, "log_input", True):
+            raise NotImplementedError("PoissonNLLLoss(log_input=False) has no HIP kernel")
+        return 0
+    if "mse" in name:
+        return 1
+    raise NotImplementedError(f"loss {spec!r}: only PoissonNLL(log_input) and MSE are built")
+
+
 class MultiModal(nn.Module):
 
     def __init__(self, encoder_embeddings: Dict[str, nn.Module], decoder_embeddings: Dict[str, nn.Module],
@@ -107,6 +121,7 @@ class MultiModal(nn.Module):
                 if m not in self.loss_mod:
                     raise Exception("Modality not implemented yet.")
             cfg = EngineConfig.from_model_config(self._model_config, mods)
+            cfg.loss_kind = {m: _loss_kind(self.loss_mod[m]) for m, _ in mods}
             self._engine = Engine(cfg, dev, dtype=self.compute_dtype, seed=self.engine_seed)
             self._engine.adopt(named)
         elif not self._engine.owns(named):

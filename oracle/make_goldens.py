@@ -400,6 +400,53 @@ def fx_loss_curve():
     save_json("loss_curve.json", res)
 
 
+def fx_loss_curve_1k():
+    """North-star curve length: 1000 optimisation steps of the reference (tiny model, dropout 0, mixed objectives)."""
+    model = build_model(tiny_model_cfg(), 12, 2, seed=7)
+    l, o = run_curve(model, 1000, 2, 8, 12, 2, total_steps=1000)
+    print("    tiny 1k curve:", l[:2], "...", l[-2:])
+    save_json("loss_curve_1k.json", dict(loss=l, objective=o, model_seed=7, B=2, T=8, n_ap=12, n_beh=2, total_steps=1000))
+
+
+CONFIG5_MODS = [("ap", 668), ("behavior", 2), ("lfp", 128)]
+
+
+def fx_config5_scalars():
+    """BASELINE.json configs[4] as SURVEY.md §8d instantiates it: H=512, I=1024, 8 heads (dh=64), T=200, three
+    modalities (L=600), 5+5 layers.  The reference defines losses for 'ap'/'behavior' only (mm.py:79-82), so 'lfp'
+    gets nn.MSELoss(reduction='none') added to model.loss_mod, as §8d prescribes.  B=2, eval mode, one padded trial."""
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import mm_oracle as O
+    m = plain(ref_config()["model"])
+    for side in ("encoder", "decoder"):
+        m[side]["embedder"].update(max_F=200, n_modality=3)
+        m[side]["transformer"].update(hidden_size=512, n_heads=8, inter_size=1024)
+    cfg = DictConfig(m)
+    torch.manual_seed(42)
+    enc = {mod: EncoderEmbedding(hidden_size=512, n_channel=n, config=cfg.encoder) for mod, n in CONFIG5_MODS}
+    dec = {mod: DecoderEmbedding(hidden_size=512, n_channel=n, output_channel=n, config=cfg.decoder) for mod, n in CONFIG5_MODS}
+    model = MultiModal(enc, dec, avail_mod=[mod for mod, _ in CONFIG5_MODS], config=cfg, share_modality_embeddings=True)
+    model.loss_mod["lfp"] = torch.nn.MSELoss(reduction="none")
+    model.eval()
+    batch = O.synth_batch_mods(2, 200, CONFIG5_MODS, seed=0, pad=[0, 7])
+    res = dict(mods=CONFIG5_MODS, B=2, T=200, pad=[0, 7], model_seed=42, batch_seed=0, masker_seed=1, cases={})
+    for case, masked in (("token_masking", None), ("mask_ap", "ap"), ("mask_lfp", "lfp")):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(1)
+        out = model(O.make_mod_dict_mods(batch, CONFIG5_MODS, masked))
+        out.loss.backward()
+        res["cases"][case] = dict(
+            loss=float(out.loss),
+            mod_loss={k: float(v) for k, v in out.mod_loss.items()},
+            n={k: int(v) for k, v in out.mod_n_examples.items()},
+            pred_abssum={k: float(v.double().abs().sum()) for k, v in out.mod_preds.items()},
+            grad_norm={k: float(p.grad.double().norm()) for k, p in model.named_parameters()})
+        print("   ", case, res["cases"][case]["loss"], res["cases"][case]["n"])
+    # a few raw values so a permutation of tokens/modalities cannot hide behind the sums
+    res["pred_samples"] = {k: [float(x) for x in out.mod_preds[k][1, 150:153, 0]] for k in out.mod_preds}
+    save_json("config5_scalars.json", res)
+
+
 def fx_trainer_io():
     """The reference trainer on 3 synthetic batches (wandb / torcheval stubbed)."""
     import transformers  # noqa: F401  (import before stubbing, SURVEY.md §8c)
@@ -511,7 +558,7 @@ def main():
     for name, fn in [("init_order", fx_init_order), ("tiny_fwd_bwd", fx_tiny_fwd_bwd),
                      ("default_scalars", fx_default_scalars), ("masker_bits", fx_masker_bits),
                      ("mask_index_ops", fx_mask_index_ops), ("sched_adamw", fx_sched_adamw),
-                     ("loss_curve", fx_loss_curve), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate)]:
+                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate)]:
         if only and name not in only:
             continue
         print(f"[{name}]")

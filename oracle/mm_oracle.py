@@ -489,6 +489,41 @@ def make_mod_dict(batch, objective, avail_mod=MODS_DEFAULT):
     return md
 
 
+def synth_batch_mods(B, T, mods, seed, pad=None):
+    """Synthetic batch for an arbitrary modality list (SURVEY.md §8d, config 5): `mods` = [(name, channels)];
+    'ap' draws Poisson(0.3) counts, every other modality N(0,1).  Same host generator recipe as synth_batch."""
+    g = torch.Generator().manual_seed(seed)
+    data = {}
+    for name, n in mods:
+        data[name] = torch.poisson(torch.full((B, T, n), 0.3), generator=g) if name == "ap" else torch.randn(B, T, n, generator=g)
+    attn = torch.ones(B, T, dtype=torch.int64)
+    if pad is not None:
+        for b, pb in enumerate(pad):
+            if pb:
+                attn[b, T - pb:] = 0
+    ts = torch.arange(T, dtype=torch.int64)[None].repeat(B, 1)
+    return dict(data=data, time_attn_mask=attn, spikes_timestamps=ts)
+
+
+def make_mod_dict_mods(batch, mods, masked=None):
+    """mod_dict for an arbitrary modality list, built the way trainer/base.py:51-103 builds it for two.
+    masked = None -> eval_mask None everywhere (token_masking: the model's masker draws the masks);
+    masked = name  -> that modality fully masked (ones), all others zeros (encoding/decoding style)."""
+    md = {}
+    for i, (name, n) in enumerate(mods):
+        x = batch["data"][name]
+        md[name] = dict(inputs_modality=torch.tensor(i), inputs_attn_mask=batch["time_attn_mask"],
+                        inputs_timestamp=batch["spikes_timestamps"], masking_mode=None,
+                        inputs=x.clone(), targets=x.clone())
+        if name == "ap":
+            md[name]["inputs_regions"] = np.full((x.shape[0], n), "XX")
+        if masked is None:
+            md[name]["eval_mask"] = None
+        else:
+            md[name]["eval_mask"] = (torch.ones_like(x) if name == masked else torch.zeros_like(x)).to(torch.int64)
+    return md
+
+
 class OracleTrainer:
     """The four hot lines of train_epoch (trainer/base.py:191-198) around `forward`."""
 

@@ -22,12 +22,13 @@ def load_config():
 
 
 def model_config(H=None, heads=None, inter=None, n_enc=None, n_dec=None, max_F=None, dropout=None, emb_dropout=None,
-                 sep=None, causal=None):
+                 sep=None, causal=None, n_modality=None):
     from utils.config_utils import DictConfig
     m = copy.deepcopy(dict(load_config()["model"]))
     for side in ("encoder", "decoder"):
         e, t = m[side]["embedder"], m[side]["transformer"]
         if max_F is not None: e["max_F"] = max_F
+        if n_modality is not None: e["n_modality"] = n_modality
         if emb_dropout is not None: e["dropout"] = emb_dropout
         if H is not None: t["hidden_size"] = H
         if heads is not None: t["n_heads"] = heads
@@ -61,6 +62,19 @@ def build_model(mcfg, n_ap, n_beh, seed=None):
         dec[mod] = DecoderEmbedding(hidden_size=mcfg.decoder.transformer.hidden_size, n_channel=n_ap if mod == "ap" else n_beh,
                                     output_channel=n_ap if mod == "ap" else n_beh, config=mcfg.decoder)
     return MultiModal(enc, dec, avail_mod=["ap", "behavior"], config=mcfg, share_modality_embeddings=True)
+
+
+def build_model_mods(mcfg, mods, seed=None):
+    """Same construction order for an arbitrary modality list [(name, channels)] (BASELINE configs[4]: 3 modalities)."""
+    from multi_modal.mm import MultiModal
+    from multi_modal.encoder_embeddings import EncoderEmbedding
+    from multi_modal.decoder_embeddings import DecoderEmbedding
+    if seed is not None:
+        torch.manual_seed(seed)
+    H = mcfg.encoder.transformer.hidden_size
+    enc = {m: EncoderEmbedding(hidden_size=H, n_channel=n, config=mcfg.encoder) for m, n in mods}
+    dec = {m: DecoderEmbedding(hidden_size=H, n_channel=n, output_channel=n, config=mcfg.decoder) for m, n in mods}
+    return MultiModal(enc, dec, avail_mod=[m for m, _ in mods], config=mcfg, share_modality_embeddings=True)
 
 
 def make_optimizer(model, total_steps, lr=1e-4, wd=0.01, eps=1e-8):

@@ -158,7 +158,9 @@ def ref_attention(q, k, v, mask, scale):
 
 
 @pytest.mark.parametrize("B,heads,L,dh,flags", [(2, 8, 200, 32, 1), (2, 8, 200, 32, 0), (3, 4, 16, 8, 1), (2, 4, 16, 8, 2),
-                                                (2, 4, 16, 8, 4), (2, 2, 70, 16, 1), (1, 8, 100, 64, 1)])
+                                                (2, 4, 16, 8, 4), (2, 2, 70, 16, 1), (1, 8, 100, 64, 1),
+                                                # tiled kernels (operands do not fit LDS): BASELINE config 5 is L=600, dh=64
+                                                (2, 8, 600, 64, 1), (2, 2, 600, 64, 0), (1, 2, 330, 32, 4), (1, 4, 620, 16, 2)])
 def test_attention_fwd_bwd(ops, B, heads, L, dh, flags):
     from multi_modal_foundation_model_amd import _lib as Lb
     H = heads * dh
@@ -201,14 +203,15 @@ def test_attention_fwd_bwd(ops, B, heads, L, dh, flags):
     close(dqkv, x.grad, rtol=1e-3, atol=5e-5, msg="attn bwd")
 
 
-def test_attention_cross_shapes(ops):
-    """Lq != Lk (no DIAG): cross attention over a longer context."""
+@pytest.mark.parametrize("Lq,Lk,dh", [(40, 72, 32), (40, 700, 64), (300, 70, 64)])
+def test_attention_cross_shapes(ops, Lq, Lk, dh):
+    """Lq != Lk (no DIAG): cross attention over a longer context (the long cases run the tiled kernels)."""
     from multi_modal_foundation_model_amd import _lib as Lb
-    B, heads, Lq, Lk, dh = 2, 4, 40, 72, 32
+    B, heads = 2, 4
     H = heads * dh
     q, kv, d_o = rnd(B * Lq, H, seed=1), rnd(B * Lk, 2 * H, seed=2), rnd(B * Lq, H, seed=3)
     kp = torch.ones(B, Lk, dtype=torch.uint8)
-    kp[1, 60:] = 0
+    kp[1, Lk - 12:] = 0
     kp = kp.cuda()
     o, lse = torch.empty(B * Lq, H, device="cuda"), torch.empty(B, heads, Lq, device="cuda")
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
@@ -227,11 +230,13 @@ def test_attention_cross_shapes(ops):
     close(dkv, kvr.grad, rtol=1e-3, atol=5e-5, msg="xattn dkv")
 
 
-def test_attention_dropout_consistency(ops):
+@pytest.mark.parametrize("L,dh", [(64, 32), (600, 64)])
+def test_attention_dropout_consistency(ops, L, dh):
     """Dropout masks are regenerated in the backward: check dV against the forward's own mask by
-    linearity: with q=k=0 all probabilities are uniform, so O = mean over kept keys of V/(1-p)."""
+    linearity: with q=k=0 all probabilities are uniform, so O = mean over kept keys of V/(1-p).
+    (600, 64) runs the tiled kernels."""
     from multi_modal_foundation_model_amd import _lib as Lb
-    B, heads, L, dh, p = 2, 4, 64, 32, 0.4
+    B, heads, p = 2, 4, 0.4
     H = heads * dh
     qkv = torch.zeros(B * L, 3 * H, device="cuda")
     qkv[:, 2 * H:] = 1.0                                    # V = 1  => O[q] = kept_fraction/(1-p)
@@ -441,7 +446,7 @@ def test_gemm_bf16_dw_splitk(ops, R, N, K, splits):
 
 
 @pytest.mark.parametrize("B,heads,L,dh,flags", [(2, 8, 200, 32, 1), (2, 8, 200, 32, 0), (2, 4, 48, 16, 2), (2, 4, 40, 16, 4), (2, 2, 70, 64, 1),
-                                                (3, 4, 16, 8, 1)])
+                                                (3, 4, 16, 8, 1), (2, 8, 600, 64, 1), (2, 2, 460, 64, 0)])
 def test_attention_bf16_fwd_bwd(ops, B, heads, L, dh, flags):
     """bf16 MFMA attention (dh 16/32/64; dh=8 falls through to fp32 compute on bf16 storage) vs an fp32
     reference on the same bf16-rounded inputs.  Tolerance: bf16 has 8 significant bits."""
@@ -479,9 +484,12 @@ def test_attention_bf16_fwd_bwd(ops, B, heads, L, dh, flags):
         close_bf16(dqkv[:, sl], x.grad[:, sl], f"bf16 attn {nm}", tol=3e-2)
 
 
-def test_attention_bf16_dropout_consistency(ops):
+@pytest.mark.parametrize("L,dh", [(64, 32), (600, 64), (460, 64)])
+def test_attention_bf16_dropout_consistency(ops, L, dh):
+    """(600, 64): neither bf16 kernel fits -> tiled fp32 compute; (460, 64): the bf16 forward alone would fit but the
+    backward does not, so the pair must move together (one dropout hash layout per forward/backward pair)."""
     from multi_modal_foundation_model_amd import _lib as Lb
-    B, heads, L, dh, p = 2, 4, 64, 32, 0.4
+    B, heads, p = 2, 4, 0.4
     H = heads * dh
     qkv = torch.zeros(B * L, 3 * H, device="cuda", dtype=torch.bfloat16)
     qkv[:, 2 * H:] = 1.0

@@ -10,7 +10,7 @@ import pytest
 import torch
 
 from conftest import load_json, load_npz
-from helpers import build_model, load_config, make_optimizer, model_config, tiny_config
+from helpers import build_model, build_model_mods, load_config, make_optimizer, model_config, tiny_config
 from oracle import mm_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -74,6 +74,57 @@ def test_default_config_scalars_vs_reference_fixture():
             assert float(prm.grad.double().norm()) == pytest.approx(g[obj]["grad_norm"][k], rel=5e-3, abs=1e-8), k
 
 
+def test_config5_three_modalities_vs_reference_fixture():
+    """BASELINE configs[4] as SURVEY.md §8d instantiates it: H=512, I=1024, dh=64, T=200, ap+behavior+lfp (L=600), 5+5
+    layers; fp32 parity mode against the reference's own forward/backward (oracle/make_goldens.py:fx_config5_scalars).
+    L=600 with dh=64 does not fit LDS: this runs the tiled attention kernels."""
+    g = load_json("config5_scalars.json")
+    mods = [tuple(m) for m in g["mods"]]
+    model = build_model_mods(model_config(H=512, heads=8, inter=1024, max_F=200, n_modality=3), mods, seed=g["model_seed"])
+    model.loss_mod["lfp"] = torch.nn.MSELoss(reduction="none")          # as upstream would add it (mm.py:79-82)
+    model = model.cuda().eval()
+    batch = O.synth_batch_mods(g["B"], g["T"], mods, seed=g["batch_seed"], pad=g["pad"])
+    for case, masked in (("token_masking", None), ("mask_ap", "ap"), ("mask_lfp", "lfp")):
+        c = g["cases"][case]
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(g["masker_seed"])
+        out = model(to_dev(O.make_mod_dict_mods(batch, mods, masked)))
+        out.loss.backward()
+        assert out.loss.item() == pytest.approx(c["loss"], rel=1e-5)
+        for m, _ in mods:
+            assert int(out.mod_n_examples[m]) == c["n"][m]
+            assert float(out.mod_preds[m].double().abs().sum()) == pytest.approx(c["pred_abssum"][m], rel=1e-4)
+        for k, prm in model.named_parameters():
+            gn = 0.0 if prm.grad is None else float(prm.grad.double().norm())
+            assert gn == pytest.approx(c["grad_norm"][k], rel=5e-3, abs=1e-8), k
+    for m, _ in mods:
+        np.testing.assert_allclose(out.mod_preds[m][1, 150:153, 0].cpu().numpy(), g["pred_samples"][m], rtol=1e-3, atol=1e-5)
+
+
+def test_config5_bf16_train_steps_finite_and_close():
+    """Same shapes in bf16 throughput mode with dropout on: three optimisation steps run (tiled attention on bf16
+    storage), the loss is finite and stays within bf16 distance of the fp32 reference value at step 0."""
+    g = load_json("config5_scalars.json")
+    mods = [tuple(m) for m in g["mods"]]
+    model = build_model_mods(model_config(H=512, heads=8, inter=1024, max_F=200, n_modality=3, dropout=0.0, emb_dropout=0.0), mods,
+                             seed=g["model_seed"])
+    model.loss_mod["lfp"] = "mse"
+    model.compute_dtype = "bf16"
+    model = model.cuda().train()
+    opt, sch = make_optimizer(model, 10)
+    batch = O.synth_batch_mods(g["B"], g["T"], mods, seed=g["batch_seed"], pad=g["pad"])
+    losses = []
+    for s in range(3):
+        torch.manual_seed(g["masker_seed"])
+        out = model(to_dev(O.make_mod_dict_mods(batch, mods, "ap")))
+        out.loss.backward()
+        opt.step(); sch.step(); opt.zero_grad()
+        losses.append(out.loss.item())
+    assert np.isfinite(losses).all()
+    assert losses[0] == pytest.approx(g["cases"]["mask_ap"]["loss"], rel=2e-2)
+    assert losses[2] < losses[0]
+
+
 def run_curve(model, steps, B, T, n_ap, n_beh, total_steps, objectives):
     opt, sch = make_optimizer(model, total_steps)
     model.train()
@@ -94,6 +145,15 @@ def test_loss_curve_tiny_50_steps_vs_reference_fixture():
     model = build_model(tiny_config(), 12, 2, seed=7).cuda()
     losses = run_curve(model, 50, 2, 8, 12, 2, 50, g["objective"])
     np.testing.assert_allclose(losses, g["loss"], rtol=1e-4)          # north star: curve within 1e-4
+
+
+def test_loss_curve_tiny_1000_steps_vs_reference_fixture():
+    """North star: 'masked-loss curve matching reference to 1e-4 over 1k synthetic steps' (reference CPU fp32 run,
+    oracle/make_goldens.py:fx_loss_curve_1k; mixed objectives, OneCycleLR over the 1000 steps, dropout 0)."""
+    g = load_json("loss_curve_1k.json")
+    model = build_model(tiny_config(), 12, 2, seed=7).cuda()
+    losses = run_curve(model, 1000, 2, 8, 12, 2, 1000, g["objective"])
+    np.testing.assert_allclose(losses, g["loss"], rtol=1e-4)
 
 
 def test_loss_curve_default_30_steps_vs_reference_fixture():
