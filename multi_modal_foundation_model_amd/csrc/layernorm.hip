@@ -7,7 +7,6 @@
 
 namespace {
 
-constexpr int MAXV = 4;  // float4 chunks per lane -> H <= 64*4*4 = 1024
 
 __device__ __forceinline__ int64_t destitch_row(int64_t r, int L, int T, int64_t Btot) {
     if (T <= 0) return r;
@@ -16,117 +15,149 @@ __device__ __forceinline__ int64_t destitch_row(int64_t r, int L, int T, int64_t
     return (int64_t)(l / T) * (Btot * T) + b * T + (l % T);
 }
 
-template <typename T>
+// NV = 256-column chunks per lane (H <= 256*NV); UNR = rows a wave keeps in flight per iteration.  The kernels are
+// latency-bound at one row per wave (16 waves/CU x 1.5 KB in flight = 3 TB/s by Little's law, measured 137 us for
+// the [204800, 256] bf16 backward = 3.07 TB/s): all loads of UNR consecutive rows are issued before the first use.
+template <typename T, int NV, int UNR>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, T* __restrict__ y,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int64_t R, int H,
                                                      float eps, int dsL, int dsT) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nv = H / 256 + ((H % 256) ? 1 : 0);
     const int64_t Btot = dsT > 0 ? R / dsL : 0;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < R; row += (int64_t)gridDim.x * 4) {
-        float4 v[MAXV];
-        float s = 0.f;
+    float4 g[NV], bt[NV];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = i * 256 + lane * 4;
-            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < nv && c < H) {
-                v[i] = io<T>::ld4(x + (size_t)row * H + c);
-                s += v[i].x + v[i].y + v[i].z + v[i].w;
+    for (int i = 0; i < NV; ++i) {
+        const int c = i * 256 + lane * 4;
+        g[i] = bt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < H) { g[i] = *reinterpret_cast<const float4*>(gamma + c); bt[i] = *reinterpret_cast<const float4*>(beta + c); }
+    }
+    const float invH = 1.f / (float)H;
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * UNR; row0 < R; row0 += (int64_t)gridDim.x * 4 * UNR) {
+        float4 v[UNR][NV];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4;
+                v[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < H && row0 + u < R) v[u][i] = io<T>::ld4(x + (size_t)(row0 + u) * H + c);
             }
-        }
-        const float mu = wave_sum(s) / (float)H;
-        float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = i * 256 + lane * 4;
-            if (i < nv && c < H) {
-                const float a = v[i].x - mu, b = v[i].y - mu, cc = v[i].z - mu, dd = v[i].w - mu;
-                q += a * a + b * b + cc * cc + dd * dd;
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t row = row0 + u;
+            if (row >= R) break;                   // wave-uniform
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) s += v[u][i].x + v[u][i].y + v[u][i].z + v[u][i].w;   // zero beyond H
+            const float mu = wave_sum(s) * invH;
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4;
+                if (c < H) {
+                    const float a = v[u][i].x - mu, b = v[u][i].y - mu, cc = v[u][i].z - mu, dd = v[u][i].w - mu;
+                    q += a * a + b * b + cc * cc + dd * dd;
+                }
             }
-        }
-        const float rs = rsqrtf(wave_sum(q) / (float)H + eps);
-        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-        const int64_t orow = destitch_row(row, dsL, dsT, Btot);
+            const float rs = rsqrtf(wave_sum(q) * invH + eps);
+            if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+            const int64_t orow = destitch_row(row, dsL, dsT, Btot);
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = i * 256 + lane * 4;
-            if (i < nv && c < H) {
-                const float4 g = *reinterpret_cast<const float4*>(gamma + c);
-                const float4 bt = *reinterpret_cast<const float4*>(beta + c);
-                float4 o;
-                o.x = (v[i].x - mu) * rs * g.x + bt.x;
-                o.y = (v[i].y - mu) * rs * g.y + bt.y;
-                o.z = (v[i].z - mu) * rs * g.z + bt.z;
-                o.w = (v[i].w - mu) * rs * g.w + bt.w;
-                io<T>::st4(y + (size_t)orow * H + c, o);
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4;
+                if (c < H) {
+                    float4 o;
+                    o.x = (v[u][i].x - mu) * rs * g[i].x + bt[i].x;
+                    o.y = (v[u][i].y - mu) * rs * g[i].y + bt[i].y;
+                    o.z = (v[u][i].z - mu) * rs * g[i].z + bt[i].z;
+                    o.w = (v[u][i].w - mu) * rs * g[i].w + bt[i].w;
+                    io<T>::st4(y + (size_t)orow * H + c, o);
+                }
             }
         }
     }
 }
 
 // dx = dres + rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat));  per-block partial dgamma/dbeta
-template <typename T>
+template <typename T, int NV, int UNR>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
                                                      const float* __restrict__ gamma, const T* dres, T* dx,
                                                      float* __restrict__ part, int64_t R, int H, int dsL, int dsT) {
     extern __shared__ __attribute__((aligned(16))) float red[];  // [4][2][H]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nv = H / 256 + ((H % 256) ? 1 : 0);
     const int64_t Btot = dsT > 0 ? R / dsL : 0;
-    float4 ag[MAXV], ab[MAXV], g[MAXV];
+    float4 ag[NV], ab[NV], g[NV];
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         ag[i] = ab[i] = g[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int c = i * 256 + lane * 4;
-        if (i < nv && c < H) g[i] = *reinterpret_cast<const float4*>(gamma + c);
+        if (c < H) g[i] = *reinterpret_cast<const float4*>(gamma + c);
     }
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < R; row += (int64_t)gridDim.x * 4) {
-        const float mu = mean[row], rs = rstd[row];
-        const int64_t yrow = destitch_row(row, dsL, dsT, Btot);
-        float4 d[MAXV], xh[MAXV];
-        float s1 = 0.f, s2 = 0.f;
+    const float invH = 1.f / (float)H;
+    for (int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * UNR; row0 < R; row0 += (int64_t)gridDim.x * 4 * UNR) {
+        float4 d[UNR][NV], xv[UNR][NV], rr[UNR][NV];
+        float mu[UNR], rs[UNR];
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = i * 256 + lane * 4;
-            d[i] = xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < nv && c < H) {
-                d[i] = io<T>::ld4(dy + (size_t)yrow * H + c);
-                const float4 xv = io<T>::ld4(x + (size_t)row * H + c);
-                xh[i] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-                ab[i].x += d[i].x; ab[i].y += d[i].y; ab[i].z += d[i].z; ab[i].w += d[i].w;
-                ag[i].x += d[i].x * xh[i].x; ag[i].y += d[i].y * xh[i].y;
-                ag[i].z += d[i].z * xh[i].z; ag[i].w += d[i].w * xh[i].w;
-                d[i].x *= g[i].x; d[i].y *= g[i].y; d[i].z *= g[i].z; d[i].w *= g[i].w;
-                s1 += d[i].x + d[i].y + d[i].z + d[i].w;
-                s2 += d[i].x * xh[i].x + d[i].y * xh[i].y + d[i].z * xh[i].z + d[i].w * xh[i].w;
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t row = row0 + u;
+            const bool ok = row < R;
+            mu[u] = ok ? mean[row] : 0.f;
+            rs[u] = ok ? rstd[row] : 0.f;
+            const int64_t yrow = ok ? destitch_row(row, dsL, dsT, Btot) : 0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4;
+                d[u][i] = xv[u][i] = rr[u][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < H && ok) {
+                    d[u][i] = io<T>::ld4(dy + (size_t)yrow * H + c);
+                    xv[u][i] = io<T>::ld4(x + (size_t)row * H + c);
+                    if (dres) rr[u][i] = io<T>::ld4(dres + (size_t)row * H + c);
+                }
             }
         }
-        const float m1 = wave_sum(s1) / (float)H, m2 = wave_sum(s2) / (float)H;
 #pragma unroll
-        for (int i = 0; i < MAXV; ++i) {
-            const int c = i * 256 + lane * 4;
-            if (i < nv && c < H) {
-                float4 o;
-                o.x = rs * (d[i].x - m1 - xh[i].x * m2);
-                o.y = rs * (d[i].y - m1 - xh[i].y * m2);
-                o.z = rs * (d[i].z - m1 - xh[i].z * m2);
-                o.w = rs * (d[i].w - m1 - xh[i].w * m2);
-                if (dres) {
-                    const float4 rr = io<T>::ld4(dres + (size_t)row * H + c);
-                    o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+        for (int u = 0; u < UNR; ++u) {
+            const int64_t row = row0 + u;
+            if (row >= R) break;                   // wave-uniform
+            float4 xh[NV];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4;
+                xh[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < H) {
+                    float4& dd = d[u][i];
+                    xh[i] = make_float4((xv[u][i].x - mu[u]) * rs[u], (xv[u][i].y - mu[u]) * rs[u], (xv[u][i].z - mu[u]) * rs[u],
+                                        (xv[u][i].w - mu[u]) * rs[u]);
+                    ab[i].x += dd.x; ab[i].y += dd.y; ab[i].z += dd.z; ab[i].w += dd.w;
+                    ag[i].x += dd.x * xh[i].x; ag[i].y += dd.y * xh[i].y; ag[i].z += dd.z * xh[i].z; ag[i].w += dd.w * xh[i].w;
+                    dd.x *= g[i].x; dd.y *= g[i].y; dd.z *= g[i].z; dd.w *= g[i].w;
+                    s1 += dd.x + dd.y + dd.z + dd.w;
+                    s2 += dd.x * xh[i].x + dd.y * xh[i].y + dd.z * xh[i].z + dd.w * xh[i].w;
                 }
-                io<T>::st4(dx + (size_t)row * H + c, o);
+            }
+            const float m1 = wave_sum(s1) * invH, m2 = wave_sum(s2) * invH;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int c = i * 256 + lane * 4;
+                if (c < H) {
+                    float4 o;
+                    o.x = rs[u] * (d[u][i].x - m1 - xh[i].x * m2) + rr[u][i].x;
+                    o.y = rs[u] * (d[u][i].y - m1 - xh[i].y * m2) + rr[u][i].y;
+                    o.z = rs[u] * (d[u][i].z - m1 - xh[i].z * m2) + rr[u][i].z;
+                    o.w = rs[u] * (d[u][i].w - m1 - xh[i].w * m2) + rr[u][i].w;
+                    io<T>::st4(dx + (size_t)row * H + c, o);
+                }
             }
         }
     }
     // cross-wave reduction of the column partials, fixed order (deterministic)
 #pragma unroll
-    for (int i = 0; i < MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = i * 256 + lane * 4;
-        if (i < nv && c < H) {
+        if (c < H) {
             *reinterpret_cast<float4*>(&red[(wave * 2 + 0) * H + c]) = ag[i];
             *reinterpret_cast<float4*>(&red[(wave * 2 + 1) * H + c]) = ab[i];
         }
@@ -160,8 +191,8 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize(const float* __restrict__
 
 // enough workgroups to fill every wave slot of the chip (256 CUs x 8 blocks of 4 waves): streaming kernels
 // hide HBM latency with waves in flight; the backward keeps fewer blocks (its per-block partials are reduced after)
-int ln_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(2048, (R + 3) / 4)); }
-int ln_bwd_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (R + 3) / 4)); }
+int ln_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(2048, (R + 15) / 16)); }
+int ln_bwd_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (R + 15) / 16)); }
 
 }  // namespace
 
@@ -175,12 +206,12 @@ extern "C" int mmfm_layernorm_fwd(int dtype, const void* x, const float* gamma, 
     MMFM_REQUIRE(dsT == 0 || (dsL > 0 && dsL % dsT == 0 && R % dsL == 0), "mmfm_layernorm_fwd: bad destitch L=%d T=%d", dsL, dsT);
     dim3 grid(ln_blocks(R)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MMFM_F32)
-        hipLaunchKernelGGL(ln_fwd_kernel<float>, grid, block, 0, st, (const float*)x, gamma, beta, (float*)y, mean, rstd, R, H, eps, dsL, dsT);
-    else if (dtype == MMFM_BF16)
-        hipLaunchKernelGGL(ln_fwd_kernel<uint16_t>, grid, block, 0, st, (const uint16_t*)x, gamma, beta, (uint16_t*)y, mean, rstd, R, H, eps, dsL, dsT);
-    else
-        return mmfm_set_error(-1, "mmfm_layernorm_fwd: bad dtype %d", dtype);
+    if (dtype != MMFM_F32 && dtype != MMFM_BF16) return mmfm_set_error(-1, "mmfm_layernorm_fwd: bad dtype %d", dtype);
+#define LN_FWD(TT, NVV, UU) hipLaunchKernelGGL((ln_fwd_kernel<TT, NVV, UU>), grid, block, 0, st, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, R, H, eps, dsL, dsT)
+#define LN_FWD_T(TT) if (H <= 256) LN_FWD(TT, 1, 4); else if (H <= 512) LN_FWD(TT, 2, 2); else LN_FWD(TT, 4, 1)
+    if (dtype == MMFM_F32) { LN_FWD_T(float); } else { LN_FWD_T(uint16_t); }
+#undef LN_FWD_T
+#undef LN_FWD
     MMFM_LAUNCH_CHECK("mmfm_layernorm_fwd");
     return 0;
 }
@@ -198,14 +229,12 @@ extern "C" int mmfm_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     const int nblk = ln_bwd_blocks(R);
     const size_t lds = (size_t)4 * 2 * H * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == MMFM_F32)
-        hipLaunchKernelGGL(ln_bwd_kernel<float>, dim3(nblk), dim3(256), lds, st, (const float*)dy, (const float*)x, mean, rstd, gamma,
-                           (const float*)dres, (float*)dx, (float*)workspace, R, H, dsL, dsT);
-    else if (dtype == MMFM_BF16)
-        hipLaunchKernelGGL(ln_bwd_kernel<uint16_t>, dim3(nblk), dim3(256), lds, st, (const uint16_t*)dy, (const uint16_t*)x, mean, rstd,
-                           gamma, (const uint16_t*)dres, (uint16_t*)dx, (float*)workspace, R, H, dsL, dsT);
-    else
-        return mmfm_set_error(-1, "mmfm_layernorm_bwd: bad dtype %d", dtype);
+    if (dtype != MMFM_F32 && dtype != MMFM_BF16) return mmfm_set_error(-1, "mmfm_layernorm_bwd: bad dtype %d", dtype);
+#define LN_BWD(TT, NVV, UU) hipLaunchKernelGGL((ln_bwd_kernel<TT, NVV, UU>), dim3(nblk), dim3(256), lds, st, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)dres, (TT*)dx, (float*)workspace, R, H, dsL, dsT)
+#define LN_BWD_T(TT) if (H <= 256) LN_BWD(TT, 1, 4); else if (H <= 512) LN_BWD(TT, 2, 2); else LN_BWD(TT, 4, 1)
+    if (dtype == MMFM_F32) { LN_BWD_T(float); } else { LN_BWD_T(uint16_t); }
+#undef LN_BWD_T
+#undef LN_BWD
     MMFM_LAUNCH_CHECK("mmfm_layernorm_bwd");
     // per-block partials [nblk][2][H] -> dgamma, dbeta (two tall-skinny slab reductions)
     if (dbeta == dgamma + H)     // adjacent in the flat gradient buffer (the engine's layout): one reduction over [2H]

@@ -54,3 +54,37 @@ def preprocess_trial(trial, target, max_T, max_N, pad_value):
                 space_attn_mask=attention_mask(max_N, pad_n).astype(np.int64), spikes_timestamps=np.arange(max_T).astype(np.int64),
                 spikes_spacestamps=np.arange(max_N).astype(np.int64), target=tgt, neuron_depths=depths, neuron_regions=regions,
                 eid=trial["eid"], choice=np.float32(trial["choice"]), block=np.float32(trial["block"]), reward=np.float32(trial["reward"]))
+
+
+def synth_session_trials(n_neurons, n_trials, T, seed, eid):
+    """Synthetic IBL-style trials of ONE session (HuggingFace column layout, loader/base.py:304-327): Poisson-like
+    sparse counts as CSR uint8, two behaviour traces of length T.  Shared by oracle/make_goldens.py and the tests so
+    the reference and the build see identical trials (BASELINE configs[2]: multi-session, neurons right-padded)."""
+    rng = np.random.default_rng(seed)
+    trials = []
+    for i in range(n_trials):
+        dense = ((rng.random((T, n_neurons)) < 0.25) * rng.integers(1, 4, (T, n_neurons))).astype(np.uint8)
+        indptr, indices, data = [0], [], []
+        for r in range(T):
+            nz = np.nonzero(dense[r])[0]
+            indices += nz.tolist()
+            data += dense[r, nz].tolist()
+            indptr.append(len(indices))
+        d = dict(spikes_sparse_data=data, spikes_sparse_indices=indices, spikes_sparse_indptr=indptr,
+                 spikes_sparse_shape=[T, n_neurons], choice=float(i % 2), block=0.2, reward=1.0, eid=eid,
+                 cluster_depths=rng.random(n_neurons).tolist(), cluster_regions=[f"R{j % 3}" for j in range(n_neurons)])
+        d["wheel-speed"] = rng.standard_normal(T).astype(np.float32).tolist()
+        d["whisker-motion-energy"] = rng.standard_normal(T).astype(np.float32).tolist()
+        trials.append(d)
+    return trials
+
+
+def collate(trials, target, max_T, max_N, pad_value):
+    """torch default_collate over preprocess_trial outputs, as numpy: stack along a new batch axis; `neuron_regions`
+    becomes a list of N lists of B strings (loader/make_loader.py:51)."""
+    outs = [preprocess_trial(t, target, max_T, max_N, pad_value) for t in trials]
+    batch = {k: np.stack([o[k] for o in outs]) for k in ("spikes_data", "time_attn_mask", "space_attn_mask", "spikes_timestamps",
+                                                          "spikes_spacestamps", "target", "neuron_depths")}
+    batch["neuron_regions"] = [[o["neuron_regions"][j] for o in outs] for j in range(max_N)]
+    batch["eid"] = [o["eid"] for o in outs]
+    return batch

@@ -552,13 +552,57 @@ def fx_loader_collate():
     save_npz("loader_collate.npz", **arrs)
 
 
+MULTISESSION = dict(neurons=[14, 9, 11, 14, 6, 12], trials=3, T=8, max_N=14, pad=-1.0, epochs=2, model_seed=7)
+
+
+def fx_multisession_curve():
+    """BASELINE configs[2]: multi-session pretraining = single-session batches (trainer/base.py:65) of sessions with
+    different neuron counts, right-padded by the loader to max_space_length with pad_value=-1 (train_multi_modal.py:
+    121-128).  The reference's make_loader -> BaseDataset -> default_collate feeds the reference model; 12 steps."""
+    import datasets
+    if not hasattr(datasets, "list_datasets"):
+        datasets.list_datasets = lambda *a, **k: []
+    from loader.make_loader import make_loader
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import loader_oracle as LO
+    ms = MULTISESSION
+    loaders = []
+    for s_id, n in enumerate(ms["neurons"]):
+        trials = LO.synth_session_trials(n, ms["trials"], ms["T"], seed=100 + s_id, eid=f"session{s_id}")
+        loaders.append(make_loader(trials, batch_size=ms["trials"], target=["wheel-speed", "whisker-motion-energy"], pad_value=ms["pad"],
+                                   max_time_length=ms["T"], max_space_length=ms["max_N"], load_meta=True, shuffle=False))
+    model = build_model(tiny_model_cfg(), ms["max_N"], 2, seed=ms["model_seed"])
+    total = ms["epochs"] * len(loaders)
+    opt, sch = make_opt(model, total)
+    model.train()
+    batches = [next(iter(l)) for l in loaders]        # (creating a DataLoader iterator draws from the default generator)
+    random.seed(42)
+    torch.manual_seed(1234)
+    losses, objs, ns = [], [], []
+    for step in range(total):
+        batch = batches[step % len(loaders)]
+        obj = random.sample(["encoding", "decoding", "token_masking"], 1)[0]
+        regions = np.asarray(batch["neuron_regions"]).T                 # trainer/base.py:57
+        b = dict(spikes_data=batch["spikes_data"].float(), target=batch["target"].float(), time_attn_mask=batch["time_attn_mask"],
+                 spikes_timestamps=batch["spikes_timestamps"])
+        out = model(make_mod_dict(b, obj, regions=regions))
+        out.loss.backward()
+        opt.step(); sch.step(); opt.zero_grad()
+        losses.append(float(out.loss.detach()))
+        objs.append(obj)
+        ns.append({k: int(v) for k, v in out.mod_n_examples.items()})
+    print("    multisession curve:", losses[:3], "...", losses[-1])
+    save_json("multisession_curve.json", dict(ms, loss=losses, objective=objs, n=ns,
+                                              final_norm={k: float(v.double().norm()) for k, v in model.state_dict().items()}))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in [("init_order", fx_init_order), ("tiny_fwd_bwd", fx_tiny_fwd_bwd),
                      ("default_scalars", fx_default_scalars), ("masker_bits", fx_masker_bits),
                      ("mask_index_ops", fx_mask_index_ops), ("sched_adamw", fx_sched_adamw),
-                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate)]:
+                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("multisession_curve", fx_multisession_curve), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate)]:
         if only and name not in only:
             continue
         print(f"[{name}]")

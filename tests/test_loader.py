@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_npz
+from conftest import load_json, load_npz
 from oracle import loader_oracle as LO
 
 TARGET = ["wheel-speed", "whisker-motion-energy"]
@@ -71,3 +71,59 @@ def test_gpu_collate_bit_exact_vs_oracle_and_fixture():
         np.testing.assert_array_equal(batch["spikes_data"][b].cpu().numpy(), ref["spikes_data"], err_msg=f"big trial {b}")
         np.testing.assert_array_equal(batch["time_attn_mask"][b].cpu().numpy(), ref["time_attn_mask"])
         np.testing.assert_array_equal(batch["space_attn_mask"][b].cpu().numpy(), ref["space_attn_mask"])
+
+
+# ------------------------------------------------------------------ BASELINE configs[2]: multi-session, padded neurons
+def _multisession_batches():
+    g = load_json("multisession_curve.json")
+    sessions = [LO.synth_session_trials(n, g["trials"], g["T"], seed=100 + i, eid=f"session{i}") for i, n in enumerate(g["neurons"])]
+    return g, sessions
+
+
+def test_multisession_oracle_vs_reference_fixture():
+    """Reference make_loader -> model over 6 sessions of 6..14 neurons padded to 14 with -1 (12 AdamW steps) against the
+    oracle's loader restatement + model restatement."""
+    import torch
+    from oracle import mm_oracle as O
+    from test_oracle_golden import default_masker_cfg
+    g, sessions = _multisession_batches()
+    cfg = O.OracleCfg(hidden=32, heads=4, inter=64, n_enc=1, n_dec=1, max_F=8, embed_dropout=0.0, dropout=0.0,
+                      channels={"ap": g["max_N"], "behavior": 2})
+    total = g["epochs"] * len(sessions)
+    tr = O.OracleTrainer(O.init_state_dict(cfg, seed=g["model_seed"]), cfg, default_masker_cfg(), total_steps=total)
+    torch.manual_seed(1234)
+    for s in range(total):
+        nb = LO.collate(sessions[s % len(sessions)], TARGET, g["T"], g["max_N"], g["pad"])
+        batch = dict(spikes_data=torch.from_numpy(nb["spikes_data"]), target=torch.from_numpy(nb["target"]).float(),
+                     time_attn_mask=torch.from_numpy(nb["time_attn_mask"]), spikes_timestamps=torch.from_numpy(nb["spikes_timestamps"]))
+        loss = tr.step(batch, g["objective"][s])
+        assert loss.item() == pytest.approx(g["loss"][s], rel=1e-4), s
+
+
+@pytest.mark.gpu
+def test_multisession_gpu_collate_and_model_vs_reference_fixture():
+    """The same 12 steps on the MI355X: mmfm_collate_csr densifies/pads each single-session batch on the device and the
+    HIP engine trains on it; loss curve against the reference's (rtol 1e-4) and final parameter norms."""
+    import torch
+    from helpers import build_model, make_optimizer, tiny_config
+    from multi_modal_foundation_model_amd.collate import collate_ibl_trials
+    from oracle import mm_oracle as O
+    g, sessions = _multisession_batches()
+    model = build_model(tiny_config(), g["max_N"], 2, seed=g["model_seed"]).cuda().train()
+    total = g["epochs"] * len(sessions)
+    opt, sch = make_optimizer(model, total)
+    torch.manual_seed(1234)
+    losses = []
+    for s in range(total):
+        batch = collate_ibl_trials(sessions[s % len(sessions)], TARGET, g["T"], g["max_N"], g["pad"], device="cuda")
+        md = O.make_mod_dict({k: batch[k] for k in ("spikes_data", "target", "time_attn_mask", "spikes_timestamps")}, g["objective"][s])
+        for d in md.values():
+            d["targets_modality"], d["targets_timestamp"] = d["inputs_modality"], d["inputs_timestamp"]
+        out = model(md)
+        out.loss.backward()
+        opt.step(); sch.step(); opt.zero_grad()
+        losses.append(out.loss.detach())
+        assert {k: int(v) for k, v in out.mod_n_examples.items()} == g["n"][s]
+    np.testing.assert_allclose([x.item() for x in losses], g["loss"], rtol=1e-4)
+    for k, v in model.state_dict().items():
+        assert float(v.double().norm()) == pytest.approx(g["final_norm"][k], rel=1e-4, abs=1e-7), k
