@@ -78,6 +78,11 @@ typedef struct {
     mmfm_dropout drop;
     const void* residual;
     int ldr;
+    float* colsum;   /* optional, dtype bf16 with a_kcontig == 0 (the dW = dY^T X launches): colsum[z*slab_stride + m] =
+                        sum over split z's k range of A(m,k), i.e. the bias gradient of the same nn.Linear, computed from
+                        the A tiles the GEMM stages anyway (replaces a separate mmfm_colsum pass over dY).  With
+                        colsum == C + M*ldc the partials sit behind each dW slab and ONE mmfm_reduce_slabs over
+                        M*N + M elements finishes weight and bias gradient together. */
 } mmfm_gemm_desc;
 int mmfm_gemm(const mmfm_gemm_desc* d, mmfm_stream stream);
 

@@ -40,7 +40,7 @@ class GemmDesc(C.Structure):
                 ("a_kcontig", C.c_int), ("b_kcontig", C.c_int), ("splits", C.c_int), ("kchunk", C.c_int),
                 ("slab_stride", C.c_int64), ("bias", C.c_void_p), ("pre_out", C.c_void_p), ("act", C.c_int),
                 ("act_scale", C.c_float), ("gradmul_pre", C.c_void_p), ("drop", Dropout), ("residual", C.c_void_p),
-                ("ldr", C.c_int)]
+                ("ldr", C.c_int), ("colsum", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):

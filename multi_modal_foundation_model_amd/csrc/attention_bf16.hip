@@ -291,6 +291,22 @@ template <bool FULL, bool DROP>
 __device__ __forceinline__ void bwdA_half(const f32x16& s, const f32x16& dpv, int s2, float (&pd)[8], float (&ds)[8], float c2, float scale,
                                           const float* lse2, const float* dlt, int qt, int key, int kh, int Lq, int Lk, const MaskCtx& mk,
                                           const Drop16& dp, uint32_t pbase, int LkH) {
+    // One hash decides a PAIR of keys (even key: low 16 bits, odd key: high 16 bits).  Here the lane is the key, so the two
+    // keys of a pair sit in neighbouring lanes and would both evaluate the same hash: instead the even lane hashes the
+    // half-tile's first four queries, the odd lane its last four, and a quad-permute DPP move swaps them (12 -> 7.5 VALU
+    // per decision; this kernel is VALU-issue bound).
+    uint32_t hq[8];
+    if (DROP) {
+        const int par = key & 1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int qmine = qt * 32 + e + 8 * (2 * s2 + par) + 4 * kh;          // = mrow(8*s2 + e + 4*par, kh)
+            const uint32_t mine = dp.hash((pbase + (uint32_t)qmine) * (uint32_t)LkH + (uint32_t)(key >> 1));
+            const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+            hq[e] = par ? other : mine;          // query e      (hashed by the even lane)
+            hq[e + 4] = par ? mine : other;      // query e + 4  (hashed by the odd lane)
+        }
+    }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int r = 8 * s2 + e;
@@ -300,7 +316,7 @@ __device__ __forceinline__ void bwdA_half(const f32x16& s, const f32x16& dpv, in
         float g = dpv[r];
         float pdrop = p;
         if (DROP) {
-            const uint32_t hsh = dp.hash((pbase + (uint32_t)q) * (uint32_t)LkH + (uint32_t)(key >> 1));
+            const uint32_t hsh = hq[e];
             const bool keep = ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= dp.t16;
             pdrop = keep ? p * dp.scale : 0.f;
             g = keep ? g * dp.scale : 0.f;

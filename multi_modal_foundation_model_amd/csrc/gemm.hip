@@ -319,6 +319,7 @@ extern "C" int mmfm_gemm(const mmfm_gemm_desc* dp, mmfm_stream stream) {
                      "mmfm_gemm: split-K writes raw partials, no epilogue");
     }
     MMFM_REQUIRE(!d.residual || d.ldr >= d.N, "mmfm_gemm: ldr too small");
+    MMFM_REQUIRE(!d.colsum || (d.dtype == MMFM_BF16 && d.a_kcontig == 0), "mmfm_gemm: colsum needs dtype bf16 and a_kcontig == 0");
     hipStream_t st = (hipStream_t)stream;
     if (d.dtype == MMFM_BF16) return mmfm_gemm_bf16_launch(&d, st);
 

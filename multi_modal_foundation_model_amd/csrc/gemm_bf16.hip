@@ -299,6 +299,13 @@ __global__ __launch_bounds__(NTHREADS, BK == 64 ? 3 : 2) void gemm_bf16_kernel(c
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        // bias gradient riding on the dW launch: the workgroups of the first tile column add up the columns of the A
+        // (= dY^T) slices they stage; 8 columns x (BK/16) k-rows per thread and slice, read back from the thread's own
+        // chunks of the LDS image (no hazard), reduced over the 16 k-row groups after the last slice.
+        const bool do_cs = ARC && d.colsum != nullptr && n0 == 0;
+        float cs[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) cs[j] = 0.f;
         const int wn_ = w + gridDim.x;
         const bool more = PERSIST && wn_ < total_items;
         int m0n = 0, n0n = 0, zn = 0, kbegn = 0, kendn = 0;
@@ -317,6 +324,17 @@ __global__ __launch_bounds__(NTHREADS, BK == 64 ? 3 : 2) void gemm_bf16_kernel(c
                     g2r<BRC, BK>(rb, B, d.ldb, n0n, kbegn, d.N, kendn, alignB, t);
                 }
             }
+            if (ARC && do_cs) {
+                const int cq = t & 15, kk0 = t >> 4;
+#pragma unroll
+                for (int p = 0; p < BK / 16; ++p) {
+                    const int kk = kk0 + 16 * p;
+                    float u[8];
+                    unpack8(*reinterpret_cast<const uint4*>(As + kk * 256 + ((cq * 16) ^ ((kk & 3) << 6))), u);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) cs[j] += u[j];
+                }
+            }
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 const bf16x8v a0 = frag<ARC, BK>(As, wm * 64, ks, lane), a1 = frag<ARC, BK>(As, wm * 64 + 32, ks, lane);
@@ -325,6 +343,20 @@ __global__ __launch_bounds__(NTHREADS, BK == 64 ? 3 : 2) void gemm_bf16_kernel(c
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+        }
+        if (ARC && do_cs) {
+            __syncthreads();                   // the last slice's operand reads are done: smem is free
+            float* red = reinterpret_cast<float*>(smem);       // [16 k-row groups][128 columns]
+            float* mine = red + (t >> 4) * 128 + (t & 15) * 8;
+            *reinterpret_cast<float4*>(mine) = make_float4(cs[0], cs[1], cs[2], cs[3]);
+            *reinterpret_cast<float4*>(mine + 4) = make_float4(cs[4], cs[5], cs[6], cs[7]);
+            __syncthreads();
+            if (t < 128 && m0 + t < d.M) {
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) sum += red[i * 128 + t];
+                d.colsum[(d.splits > 1 ? (size_t)z * d.slab_stride : 0) + m0 + t] = sum;
             }
         }
         epilogue_tile<TO>(d, acc, smem, m0, n0, z, vec_epi, t, wm, wn, kh, l31);

@@ -307,10 +307,10 @@ class Engine:
         for _, n in c.mods:
             for (mm, nn) in ((n * c.mult, n), (H, n * c.mult), (n, H)):
                 S, _ = self._dw_split(mm, nn, BT)
-                max_slab = max(max_slab, S * mm * nn)
+                max_slab = max(max_slab, S * _align(mm * nn + mm))
         for (mm, nn) in ((3 * H, H), (H, H), (2 * H, H), (I, H), (H, I)):
             S, _ = self._dw_split(mm, nn, R)
-            max_slab = max(max_slab, S * mm * nn)
+            max_slab = max(max_slab, S * _align(mm * nn + mm))
         slab = buf("ws/slab", (max_slab,), f32)
         maxN = max([3 * H, I] + [n * c.mult for _, n in c.mods])
         ws_col = buf("ws/col", (max(1, L.lib().mmfm_colsum_workspace(R, maxN) // 4),), f32)
@@ -325,14 +325,25 @@ class Engine:
         def dlin(plan, dY, X, wname, Mr, N, Kd, dX=None, **kw):
             """Backward of Y[Mr,N] = X[Mr,Kd] @ W[N,Kd]^T + b:  dW, db into G;  dX = dY @ W (optional, fused epilogue)."""
             S, kchunk = self._dw_split(N, Kd, Mr)
-            gw = self.Gv(wname + ".weight")
+            gw, gb = self.Gv(wname + ".weight"), self.Gv(wname + ".bias")
+            # bf16: the bias gradient (column sums of dY) rides on the dW GEMM (mmfm_gemm_desc.colsum); when the bias
+            # gradient sits right behind the weight gradient in the flat buffer one slab reduction finishes both
+            fused = code == L.BF16
+            adjacent = fused and gb.data_ptr() == gw.data_ptr() + 4 * N * Kd
             if S == 1:
-                K.gemm(dY, X, gw, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, dtype=code, c_f32=1, plan=plan)
+                K.gemm(dY, X, gw, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, dtype=code, c_f32=1,
+                       colsum=gb if fused else None, plan=plan)
+            elif adjacent:
+                stride = _align(N * Kd + N)
+                K.gemm(dY, X, slab, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
+                       slab_stride=stride, dtype=code, c_f32=1, colsum=slab.data_ptr() + 4 * N * Kd, plan=plan)
+                K.reduce_slabs(gw, slab, N * Kd + N, S, stride, plan=plan)
             else:
                 K.gemm(dY, X, slab, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
                        slab_stride=N * Kd, dtype=code, c_f32=1, plan=plan)
                 K.reduce_slabs(gw, slab, N * Kd, S, N * Kd, plan=plan)
-            K.colsum(dY, Mr, N, N, self.Gv(wname + ".bias"), ws_col, plan=plan)
+            if not fused or (S > 1 and not adjacent):
+                K.colsum(dY, Mr, N, N, gb, ws_col, plan=plan)
             if dX is not None:
                 K.gemm(dY, self.W(wname + ".weight"), dX, Mr, Kd, N, lda=N, ldb=Kd, ldc=Kd, b_kcontig=0, dtype=code, plan=plan, **kw)
 

@@ -50,7 +50,7 @@ def dropout(state, site, p):
 
 def gemm(A, B, Cout, M, N, K, *, lda, ldb, ldc, a_kcontig=1, b_kcontig=1, bias=None, pre_out=None, act=0,
          act_scale=1.0, gradmul_pre=None, drop=None, residual=None, ldr=0, splits=1, kchunk=0, slab_stride=0,
-         dtype=None, c_f32=0, plan=None):
+         dtype=None, c_f32=0, colsum=None, plan=None):
     d = L.GemmDesc()
     d.dtype = dt(A) if dtype is None else dtype
     d.c_f32 = c_f32
@@ -61,6 +61,7 @@ def gemm(A, B, Cout, M, N, K, *, lda, ldb, ldc, a_kcontig=1, b_kcontig=1, bias=N
     d.bias, d.pre_out, d.act, d.act_scale, d.gradmul_pre = P(bias), P(pre_out), act, act_scale, P(gradmul_pre)
     d.drop = drop if drop is not None else L.NO_DROP
     d.residual, d.ldr = P(residual), ldr
+    d.colsum = colsum if isinstance(colsum, int) else P(colsum)
     _emit(plan, L.lib().mmfm_gemm, (C.byref(d),), keep=(d,))
 
 

@@ -445,6 +445,28 @@ def test_gemm_bf16_dw_splitk(ops, R, N, K, splits):
     close_bf16(dw, ref, "bf16 dW", tol=2e-3)          # fp32 accumulate of exact bf16 products
 
 
+@pytest.mark.parametrize("R,N,K,splits", [(3200, 256, 256, 8), (1000, 668, 256, 4), (777, 1336, 668, 3), (640, 2, 256, 2), (3200, 768, 256, 1),
+                                          (900, 4, 2, 2), (51200, 512, 256, 40)])
+def test_gemm_bf16_dw_with_fused_bias_grad(ops, R, N, K, splits):
+    """mmfm_gemm_desc.colsum: the bias gradient (column sums of dY) computed by the dW launch, its partials stored
+    behind each weight slab so that one slab reduction yields [dW | db] (the flat gradient buffer's layout)."""
+    dy, x = bf(rnd(R, N, seed=8)), bf(rnd(R, K, seed=9))
+    ref_w, ref_b = dy.double().T @ x.double(), dy.double().sum(0)
+    out = torch.full((N * K + N,), float("nan"), device="cuda")
+    if splits == 1:
+        ops.gemm(dy, x, out, N, K, R, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0, c_f32=1, colsum=out.data_ptr() + 4 * N * K)
+    else:
+        kchunk = ((R + splits - 1) // splits + 63) // 64 * 64
+        splits = (R + kchunk - 1) // kchunk
+        stride = (N * K + N + 7) // 8 * 8
+        slabs = torch.full((splits, stride), float("nan"), device="cuda")
+        ops.gemm(dy, x, slabs, N, K, R, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0, splits=splits, kchunk=kchunk, slab_stride=stride,
+                 c_f32=1, colsum=slabs.data_ptr() + 4 * N * K)
+        ops.reduce_slabs(out, slabs, N * K + N, splits, stride)
+    close_bf16(out[:N * K].view(N, K), ref_w, "bf16 dW (fused)", tol=2e-3)
+    close(out[N * K:], ref_b.float(), rtol=1e-5, atol=1e-4 * math.sqrt(R), msg="fused bias grad")
+
+
 @pytest.mark.parametrize("B,heads,L,dh,flags", [(2, 8, 200, 32, 1), (2, 8, 200, 32, 0), (2, 4, 48, 16, 2), (2, 4, 40, 16, 4), (2, 2, 70, 64, 1),
                                                 (3, 4, 16, 8, 1), (2, 8, 600, 64, 1), (2, 2, 460, 64, 0)])
 def test_attention_bf16_fwd_bwd(ops, B, heads, L, dh, flags):
