@@ -600,6 +600,222 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
     }
 }
 
+// ============================================================================ single-pass backward (Lk <= 224)
+// The two-phase backward above evaluates the softmax / dropout / dS algebra twice (once per phase) and both phases are
+// VALU-issue bound (SQ_ACTIVE_INST_ANY 70-85 % of the SIMD cycles, MFMA 16 %).  Here it is evaluated ONCE:
+//   waves 0..6 each own one 32-key tile (a 200-token head has exactly 7) and walk the query tiles in lock step, exactly
+//     like phase 0 (dK^T, dV^T in accumulators), and additionally drop their packed bf16 dS^T tile [32 keys][32 q] into
+//     an LDS staging slot (two 8-B writes per half tile straight from the MFMA operand registers);
+//   wave 7 - the wave a 7-tile head leaves idle - turns the staged tiles of the previous query tile into
+//     dQ^T[d][q] = sum_key K^T[d][key] dS^T[key][q] (K^T operands live in its registers for the whole kernel; the staged
+//     tiles are read with the hardware-transposed ds_read_b64_tr_b16 in the same k order) and streams dQ out.
+// One workgroup barrier per query tile hands a staging buffer over (double buffered).  Fixed summation order, no
+// atomics: bitwise reproducible.  dK/dV leave through the workgroup's own, by then dead, Q/dO images.
+constexpr int BW1_NW = 8, BW1_CW = 7, BW1_TS = 80, BW1_TILE = 32 * BW1_TS;
+
+// PIPE: issue S/dP of query tile qt+1 before the element-wise work of tile qt (costs 32 VGPRs; at dh <= 32 the kernel runs
+// four waves per SIMD under a 128-VGPR cap and lets the other waves cover the MFMA latency instead)
+template <int DH, bool PIPE>
+__global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_kernel(const mmfm_attn_desc d) {
+    constexpr int NW = BW1_NW, CW = BW1_CW, TS = BW1_TS, TILE = BW1_TILE;
+    constexpr int KS = DH / 16, DT = (DH + 31) / 32;
+    constexpr int RS = DH * 2 + 16;
+    constexpr int NT = NW * 64;
+    constexpr int C8 = DH / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, kh = lane >> 5, l31 = lane & 31;
+    // the wave index as a SCALAR: the two roles below then sit behind a uniform branch and share the register file
+    // (a branch on a per-lane value keeps the other side's live values allocated: 165 instead of ~110 VGPRs)
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int Lq = d.Lq, Lk = d.Lk, LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31, Lmx = max(Lq, Lk);
+    char* As = smem;                                  // Q image
+    char* Bs = As + LqP * RS;                         // dO image (output dropout applied)
+    float* lse2 = reinterpret_cast<float*>(Bs + LqP * RS);
+    float* dlt = lse2 + LqP;
+    char* stg = reinterpret_cast<char*>(dlt + LqP);   // [2][CW][32 keys x TS] dS^T tiles; first the K image (prologue only)
+    char* sc7 = stg + 2 * CW * TILE;                  // [32 x RS] dQ transpose tile of wave 7
+    int* wflag = reinterpret_cast<int*>(sc7 + 32 * RS);
+    uint8_t* kpad = reinterpret_cast<uint8_t*>(wflag + NW);
+    uint8_t* modl = kpad + LkP;
+    const uint16_t* qg = reinterpret_cast<const uint16_t*>(d.q) + (size_t)b * Lq * d.ldq + h * DH;
+    const uint16_t* kg = reinterpret_cast<const uint16_t*>(d.k) + (size_t)b * Lk * d.ldk + h * DH;
+    const uint16_t* vg = reinterpret_cast<const uint16_t*>(d.v) + (size_t)b * Lk * d.ldv + h * DH;
+    const uint16_t* og = reinterpret_cast<const uint16_t*>(d.o) + (size_t)b * Lq * d.ldo + h * DH;
+    const uint16_t* dog = reinterpret_cast<const uint16_t*>(d.d_o) + (size_t)b * Lq * d.lddo + h * DH;
+    const Drop16 dp = drop16_init(d.drop_p);
+    const Drop dout = drop_init(d.drop_o);
+
+    load_head16<DH>(As, RS, RS / 16, qg, d.ldq, Lq, LqP, t, NT);
+    load_head16<DH>(stg, RS, RS / 16, kg, d.ldk, Lk, LkP, t, NT);          // K image, for wave 7's K^T operands only
+    for (int idx = t; idx < LqP * C8; idx += NT) {                          // dO = dropout'(d_o) as bf16;  delta = rowsum(d_o * o)
+        const int row = idx / C8, c = idx % C8;
+        uint4 g = make_uint4(0u, 0u, 0u, 0u), o = g;
+        if (row < Lq) {
+            g = *reinterpret_cast<const uint4*>(dog + (size_t)row * d.lddo + 8 * c);
+            o = *reinterpret_cast<const uint4*>(og + (size_t)row * d.ldo + 8 * c);
+        }
+        const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, ow[4] = {o.x, o.y, o.z, o.w};
+        const uint64_t base = ((uint64_t)b * Lq + (uint64_t)row) * (uint64_t)(d.heads * DH) + (uint64_t)(h * DH + 8 * c);
+        float part = 0.f, gd[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float g0 = __uint_as_float(gw[j] << 16), g1 = __uint_as_float(gw[j] & 0xffff0000u);
+            const float o0 = __uint_as_float(ow[j] << 16), o1 = __uint_as_float(ow[j] & 0xffff0000u);
+            part += g0 * o0 + g1 * o1;
+            gd[2 * j] = dout.apply(g0, base + 2 * j);
+            gd[2 * j + 1] = dout.apply(g1, base + 2 * j + 1);
+        }
+#pragma unroll
+        for (int off = 1; off < C8; off <<= 1) part += __shfl_xor(part, off);
+        if (c == 0) dlt[row] = part;
+        *reinterpret_cast<uint4*>(Bs + row * RS + c * 16) = __builtin_bit_cast(uint4, pack8(gd));
+    }
+    constexpr int PADC = RS / 16 - C8;
+    for (int idx = t; idx < LqP * PADC; idx += NT)
+        *reinterpret_cast<uint4*>(Bs + (idx / PADC) * RS + (C8 + idx % PADC) * 16) = make_uint4(0u, 0u, 0u, 0u);
+    for (int i = t; i < LqP; i += NT) lse2[i] = (i < Lq) ? d.lse[(size_t)blockIdx.x * Lq + i] * LOG2E : 0.f;
+    int allk = 1;
+    for (int i = t; i < LkP; i += NT) {
+        const uint8_t v = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
+        kpad[i] = v;
+        if (i < Lk) allk &= (v != 0);
+    }
+    if (d.flags & MMFM_ATTN_SEP)
+        for (int i = t; i < Lmx; i += NT) modl[i] = d.mod_id[i];
+    const int wave_vote = __all(allk) ? 1 : 0;
+    if (lane == 0) wflag[wave] = wave_vote;
+    __syncthreads();
+    int vote = 1;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) vote &= wflag[w];
+    const bool nomask = vote && !(d.flags & (MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP));
+
+    const MaskCtx mk{kpad, modl, d.flags};
+    const int nqt = LqP / 32, nkt = LkP / 32, LkH = (Lk + 1) >> 1;        // nkt <= CW (launcher)
+    const uint32_t pbase = (uint32_t)blockIdx.x * (uint32_t)Lq;
+    const float c2 = d.scale * LOG2E;
+
+    if (wave < CW) {
+        // ---------------- compute waves: one key tile each, all query tiles
+        const int kt = wave;
+        const bool active = kt < nkt;
+        f32x16 dKt[DT], dVt[DT];
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dKt[i][r] = 0.f; dVt[i][r] = 0.f; }
+        const int key = kt * 32 + l31;
+        bf16x8v kfr[KS], vfr[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
+            if (active && key < Lk) {
+                kv = *reinterpret_cast<const uint4*>(kg + (size_t)key * d.ldk + ks * 16 + 8 * kh);
+                vv = *reinterpret_cast<const uint4*>(vg + (size_t)key * d.ldv + ks * 16 + 8 * kh);
+            }
+            kfr[ks] = __builtin_bit_cast(bf16x8v, kv);
+            vfr[ks] = __builtin_bit_cast(bf16x8v, vv);
+        }
+        f32x16 s_next, dp_next;
+        auto scoresA = [&](int qt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s_next[r] = 0.f; dp_next[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int off = (qt * 32 + l31) * RS + ks * 32 + kh * 16;
+                s_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(As, off), kfr[ks], s_next, 0, 0, 0);        // S[q][key]
+                dp_next = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Bs, off), vfr[ks], dp_next, 0, 0, 0);     // dP[q][key]
+            }
+        };
+        __syncthreads();                               // wave 7 has its K^T operands: the K image is dead, the staging slots free
+        if (PIPE && active) scoresA(0);
+        for (int qt = 0; qt < nqt; ++qt) {
+            if (active) {
+                if (!PIPE) scoresA(qt);
+                const f32x16 s = s_next, dpv = dp_next;
+                if (PIPE && qt + 1 < nqt) scoresA(qt + 1);
+                const bool full = nomask && (kt * 32 + 32 <= Lk) && (qt * 32 + 32 <= Lq);
+                char* slot = stg + ((qt & 1) * CW + wave) * TILE + l31 * TS;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    float pd[8], ds[8];
+                    if (full) {
+                        if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
+                        else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
+                    } else {
+                        if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
+                        else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
+                    }
+                    const bf16x8v pf = pack8(pd), sf = pack8(ds);
+                    // dS^T[key = lane][q]: elements 0..3 are queries 16*s2 + 4*kh + 0..3, elements 4..7 the same + 8
+                    const uint4 sw = __builtin_bit_cast(uint4, sf);
+                    *reinterpret_cast<uint2*>(slot + (16 * s2 + 4 * kh) * 2) = make_uint2(sw.x, sw.y);
+                    *reinterpret_cast<uint2*>(slot + (16 * s2 + 8 + 4 * kh) * 2) = make_uint2(sw.z, sw.w);
+#pragma unroll
+                    for (int i = 0; i < DT; ++i) {
+                        dVt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Bs, RS, qt * 32 + 16 * s2, i * 32, lane), pf, dVt[i], 0, 0, 0);
+                        dKt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(As, RS, qt * 32 + 16 * s2, i * 32, lane), sf, dKt[i], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();                           // staging buffer (qt & 1) is complete; buffer ((qt+1) & 1) has been consumed
+        }
+        // Q / dO images are dead (every compute wave passed the last barrier): rows [32w, 32w+32) carry this wave's stores
+        if (active) {
+            store_tile_T<DH, DT>(As + 32 * wave * RS, RS, dKt, reinterpret_cast<uint16_t*>(d.dk) + (size_t)b * Lk * d.lddk + h * DH, d.lddk,
+                                 kt * 32, Lk, lane);
+            store_tile_T<DH, DT>(Bs + 32 * wave * RS, RS, dVt, reinterpret_cast<uint16_t*>(d.dv) + (size_t)b * Lk * d.lddv + h * DH, d.lddv,
+                                 kt * 32, Lk, lane);
+        }
+    } else {
+        // ---------------- wave 7: K^T operands of every key tile, hardware-transposed out of the K image and kept for the
+        // whole kernel; then dQ of query tile qt from the staged dS^T tiles
+        bf16x8v kT[CW][2][DT];
+#pragma unroll
+        for (int kt = 0; kt < CW; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < DT; ++i) kT[kt][s2][i] = trfrag(stg, RS, min(kt, nkt - 1) * 32 + 16 * s2, i * 32, lane);
+        __syncthreads();
+        uint16_t* dqg = reinterpret_cast<uint16_t*>(d.dq) + (size_t)b * Lq * d.lddq + h * DH;
+        for (int qt = 0; qt < nqt; ++qt) {
+            __syncthreads();
+            f32x16 dQt[DT];
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dQt[i][r] = 0.f;
+            const char* buf = stg + (qt & 1) * CW * TILE;
+#pragma unroll
+            for (int kt = 0; kt < CW; ++kt) {
+                if (kt < nkt) {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const bf16x8v bfr = trfrag(buf + kt * TILE, TS, 16 * s2, 0, lane);
+#pragma unroll
+                        for (int i = 0; i < DT; ++i) dQt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[kt][s2][i], bfr, dQt[i], 0, 0, 0);
+                    }
+                }
+            }
+            store_tile_T<DH, DT>(sc7, RS, dQt, dqg, d.lddq, qt * 32, Lq, lane);
+        }
+    }
+}
+
+size_t bwd1_lds(int Lq, int Lk, int dh) {
+    const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31, RS = dh * 2 + 16;
+    return (size_t)2 * LqP * RS + (size_t)2 * LqP * 4 + (size_t)2 * BW1_CW * BW1_TILE + (size_t)32 * RS + BW1_NW * 4 + LkP + std::max(Lq, Lk) + 64;
+}
+// shapes the single-pass backward takes: one key tile per compute wave, the K image fits the staging area, the dK/dV
+// store tiles fit the Q/dO images
+bool bwd1_ok(int Lq, int Lk, int dh) {
+    const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31, RS = dh * 2 + 16;
+    static const bool off = [] { const char* e = getenv("MMFM_ATTN_BWD_SINGLE"); return e && atoi(e) == 0; }();
+    return !off && LkP <= 32 * BW1_CW && LkP <= LqP && (size_t)LkP * RS <= (size_t)2 * BW1_CW * BW1_TILE && bwd1_lds(Lq, Lk, dh) <= 160 * 1024;
+}
+
 // waves per workgroup (MMFM_ATTN_FWD_WAVES / MMFM_ATTN_BWD_WAVES = 4 or 8).  Smaller workgroups let more of them
 // co-reside on a CU, which is what hides each workgroup's dispatch + load prologue.
 int env_waves(const char* name, int dflt) {
@@ -652,6 +868,19 @@ int mmfm_attn_bf16_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st
         const bool alb = d.lddo % 8 == 0 && d.lddq % 8 == 0 && d.lddk % 8 == 0 && d.lddv % 8 == 0 && (uintptr_t)d.d_o % 16 == 0 &&
                          (uintptr_t)d.dq % 16 == 0 && (uintptr_t)d.dk % 16 == 0 && (uintptr_t)d.dv % 16 == 0;
         if (!alb) return -1000;
+        if (bwd1_ok(d.Lq, d.Lk, d.dh)) {
+            const size_t lds = bwd1_lds(d.Lq, d.Lk, d.dh);
+#define BWD1S(DHV)                                                                                                \
+            {                                                                                                     \
+                auto kern = attn_bwd1_bf16_kernel<DHV, (DHV > 32)>;                                                         \
+                if (int rc = opt_in_lds(reinterpret_cast<const void*>(kern), lds)) return rc;                     \
+                hipLaunchKernelGGL(kern, dim3(d.B * d.heads), dim3(BW1_NW * 64), lds, st, d);                     \
+            }
+            if (d.dh == 16) BWD1S(16) else if (d.dh == 32) BWD1S(32) else BWD1S(64)
+#undef BWD1S
+            MMFM_LAUNCH_CHECK("mmfm_attn_bwd(bf16, single pass)");
+            return 0;
+        }
         const int nw = bwd_waves();
         const size_t lds0 = bwd_lds(d.Lq, d.Lk, d.dh, nw, 0), lds1 = bwd_lds(d.Lq, d.Lk, d.dh, nw, 1);
         if (lds0 > 160 * 1024 || lds1 > 160 * 1024) return -1000;
