@@ -163,8 +163,10 @@ int mmfm_stitch_fwd(int dtype, const void* tok, const float* mod_emb_row, const 
  * d_mod_row (+)= sum_{b,t} (dx + dextra);  d_pos[ts[b][t]] (+)= dx + dextra  (dextra may be NULL:
  * it is d_context -> encoder_emb, mm.py:292).  acc_mod / acc_pos select += for each output (the
  * modality embedding is shared by the encoder and decoder tokenisers, mm.py:84-87, the position
- * tables are not).  Deterministic two-stage scatter (no atomics). */
-int64_t mmfm_stitch_bwd_workspace(int B, int T, int H, int max_F);
+ * tables are not).  Deterministic (no atomics): fp32 mode scatters through per-column LDS tables and reduces the
+ * per-chunk partials; bf16 mode (H % 8 == 0) multiplies by a one-hot matrix on the MFMA GEMM ([d_pos; d_mod] = OH^T E,
+ * split-K slabs, fixed-order reduction). */
+int64_t mmfm_stitch_bwd_workspace(int dtype, int B, int T, int L, int H, int max_F);
 int mmfm_stitch_bwd(int dtype, const void* dx, const void* dextra, const int64_t* ts, const uint8_t* keep0,
                     mmfm_dropout drop, void* d_tok, float* d_mod_row, float* d_pos, int acc_mod, int acc_pos,
                     int B, int T, int L, int m, int H, int max_F,

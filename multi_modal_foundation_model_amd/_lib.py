@@ -71,7 +71,7 @@ _PROTOS = {
     "mmfm_mask_prep": (C.c_int, [_i, _i, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmfm_collate_csr": (C.c_int, [_i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmfm_stitch_fwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
-    "mmfm_stitch_bwd_workspace": (C.c_int64, [_i, _i, _i, _i]),
+    "mmfm_stitch_bwd_workspace": (C.c_int64, [_i, _i, _i, _i, _i, _i]),
     "mmfm_stitch_bwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, Dropout, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _i64, _vp]),
     "mmfm_masked_loss_workspace": (C.c_int64, [_i64, _i]),
     "mmfm_masked_loss_fwd": (C.c_int, [_i, _i, _vp, _vp, _vp, _i, _i, _i64, _i, _vp, _vp, _i64, _vp]),

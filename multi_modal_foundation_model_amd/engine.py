@@ -315,7 +315,7 @@ class Engine:
         maxN = max([3 * H, I] + [n * c.mult for _, n in c.mods])
         ws_col = buf("ws/col", (max(1, L.lib().mmfm_colsum_workspace(R, maxN) // 4),), f32)
         ws_ln = buf("ws/ln", (max(1, L.lib().mmfm_layernorm_bwd_workspace(R, H) // 4),), f32)
-        ws_st = buf("ws/stitch", (max(1, L.lib().mmfm_stitch_bwd_workspace(B, T, H, c.max_F) // 4),), f32)
+        ws_st = buf("ws/stitch", (max(1, L.lib().mmfm_stitch_bwd_workspace(code, B, T, Lq, H, c.max_F) // 4),), f32)
         ws_loss = buf("ws/loss", (max(1, L.lib().mmfm_masked_loss_workspace(BT, 1) // 4),), f32)
 
         def lin(plan, X, wname, Y, Mr, N, Kd, **kw):

@@ -322,6 +322,41 @@ def test_stitch_fwd_bwd(ops):
         close(d_pos, poss[m].grad, atol=1e-4, msg="d_pos overwritten")
 
 
+@pytest.mark.parametrize("B,T,M,H,max_F,with_drop", [(5, 7, 2, 32, 9, False), (40, 100, 2, 256, 100, True), (3, 200, 3, 512, 200, False)])
+def test_stitch_bwd_bf16_onehot_gemm(ops, B, T, M, H, max_F, with_drop):
+    """bf16 mode: the position/modality-embedding gradients are a one-hot matrix product on the MFMA GEMM.  fp32
+    accumulation of bf16 values -> compare against an fp64 scatter of the same bf16 inputs."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    L = M * T
+    g = torch.Generator().manual_seed(3)
+    ts = torch.randint(0, max_F, (B, T), generator=g).cuda()
+    keep0 = (torch.rand(L, generator=g) > 0.3).to(torch.uint8).cuda()
+    dx, dextra = bf(rnd(B, L, H, seed=40)), bf(rnd(B, L, H, seed=41))
+    ws = torch.empty(Lb.lib().mmfm_stitch_bwd_workspace(Lb.BF16, B, T, L, H, max_F), dtype=torch.uint8, device="cuda")
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 11)
+    for m in range(M):
+        for extra in (dextra, None):
+            d_tok = torch.full((B * T, H), float("nan"), device="cuda", dtype=torch.bfloat16)
+            d_mod, d_pos = torch.empty(H, device="cuda"), torch.empty(max_F, H, device="cuda")
+            drop = ops.dropout(state, 5, 0.2) if with_drop else None
+            ops.stitch_bwd(dx, extra, ts, keep0, drop, d_tok, d_mod, d_pos, False, False, B, T, L, m, H, max_F, ws)
+            e = dx[:, m * T:(m + 1) * T].double() + (extra[:, m * T:(m + 1) * T].double() if extra is not None else 0)
+            ref_pos = torch.zeros(max_F, H, dtype=torch.float64, device="cuda").index_add_(0, ts.reshape(-1), e.reshape(B * T, H))
+            close(d_pos, ref_pos.float(), rtol=1e-5, atol=1e-4 * math.sqrt(B), msg="d_pos (one-hot GEMM)")
+            close(d_mod, e.sum((0, 1)).float(), rtol=1e-5, atol=1e-4 * math.sqrt(B * T), msg="d_mod (one-hot GEMM)")
+            tok_ref = dx[:, m * T:(m + 1) * T].reshape(B * T, H).float() * keep0[m * T:(m + 1) * T].repeat(B)[:, None]
+            if with_drop:
+                kept = d_tok.float() != 0
+                close(d_tok.float()[kept], (tok_ref / 0.8)[kept], rtol=1e-2, atol=1e-3, msg="d_tok kept values")
+                frac = kept.float().sum() / (tok_ref != 0).float().sum()
+                assert abs(frac.item() - 0.8) < 0.02
+            else:
+                assert torch.equal(d_tok.float(), tok_ref)
+            ops.stitch_bwd(dx, extra, ts, keep0, drop, d_tok, d_mod, d_pos, True, False, B, T, L, m, H, max_F, ws)
+            close(d_mod, 2 * e.sum((0, 1)).float(), rtol=1e-5, atol=2e-4 * math.sqrt(B * T), msg="d_mod accumulated")
+
+
 @pytest.mark.parametrize("kind,N", [(0, 668), (1, 2), (0, 12)])
 def test_masked_loss(ops, kind, N):
     B, T = 6, 10
