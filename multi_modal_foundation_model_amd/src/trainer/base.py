@@ -55,6 +55,7 @@ class MultiModalTrainer():
         # host-side constants of the batch -> mod_dict translation, built once instead of every step: the
         # modality-index scalars (a pageable H2D copy each = a stream drain per call) and the [B, N] region array
         self._mod_index_cache = {}
+        self._const_mask_cache = {}
         self._regions_cache = (None, None)
 
     # ------------------------------------------------------------------ batch -> mod_dict (trainer/base.py:51-103)
@@ -65,7 +66,12 @@ class MultiModalTrainer():
         spikes, behav = batch['spikes_data'], batch['target']
 
         def const_mask(like, value):
-            return torch.full(like.shape, value, dtype=torch.int64, device=like.device)
+            # upstream materialises torch.ones_like(x).to(int64) / zeros (547 MB per mask at B=1024, up to four per step);
+            # the model only ever reads mask[:, :, 0] (mm.py:270), so an expanded view of one cached element is equivalent
+            key = (value, str(like.device))
+            if key not in self._const_mask_cache:
+                self._const_mask_cache[key] = torch.full((1, 1, 1), value, dtype=torch.int64, device=like.device)
+            return self._const_mask_cache[key].expand(like.shape)
 
         mod_dict = {}
         for mod, idx in self.mod_to_indx.items():
@@ -80,13 +86,15 @@ class MultiModalTrainer():
                 'num_neuron': spikes.shape[2], 'masking_mode': masking_mode,
             }
             if mod == 'ap':
-                d['inputs'], d['targets'] = spikes.clone(), spikes.clone()
+                # (upstream clones twice; nothing on this path writes into either tensor - the masker works on its own
+                # clone and the engine copies inputs/targets into its static buffers - so the 2 x 274 MB copies are dropped)
+                d['inputs'], d['targets'] = spikes, spikes
                 regions = batch['neuron_regions']
                 if self._regions_cache[0] is not regions:          # same session object -> same [B, N] array
                     self._regions_cache = (regions, np.asarray(regions).T)
                 d['inputs_regions'] = self._regions_cache[1]
             elif mod == 'behavior':
-                d['inputs'], d['targets'] = behav.clone(), behav.clone()
+                d['inputs'], d['targets'] = behav, behav
             else:
                 raise Exception(f"Modality not implemented yet.")
             d['eval_mask'] = const_mask(spikes, 1 if (single_modal and mod in self.modal_filter['output']) else 0)
