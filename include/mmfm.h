@@ -215,6 +215,20 @@ int mmfm_cast_f32_to_bf16(const float* src, void* dst, int64_t n, mmfm_stream st
 int mmfm_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n,
                     const float* hyper, mmfm_stream stream);
 
+/* ---------------------------------------------------------------------------------- evaluation metrics
+ * utils/utils.py:107-115 (metrics_list "r2" = torcheval R2Score per series; trainer/base.py:252-262 calls it for 50
+ * neurons x every trial on the host):  out[g*C + c] = 1 - sum_s (y-p)^2 / sum_s (y - mean_s y)^2 over the S elements
+ * y = gt[g*gs[0] + s*gs[1] + c*gs[2]] (element strides, so transposed / sliced views need no copy), fp64 sums.
+ * A constant series gives -inf / nan like the reference; the caller masks invalids (np.ma.masked_invalid). */
+int mmfm_r2_series(const float* gt, const int64_t* gt_strides, const float* pred, const int64_t* pred_strides,
+                   int G, int S, int C, float* out, mmfm_stream stream);
+/* utils/eval_utils.py:1051-1119 (neg_log_likelihood, bits_per_spike): rates, spikes fp32 [R][N] (R = trials x bins);
+ * out[0] = bits per spike, out[1] = nll(model), out[2] = nll(null = per-neuron mean rate), out[3] = total spikes.
+ * rates == 0 -> 1e-9 as upstream; NaN spikes are not supported (upstream masks them). */
+int64_t mmfm_bits_per_spike_workspace(int64_t R, int N);
+int mmfm_bits_per_spike(const float* rates, const float* spikes, int64_t R, int N, float* out,
+                        void* workspace, int64_t workspace_bytes, mmfm_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,9 @@ _PROTOS = {
     "mmfm_dropout_apply": (C.c_int, [_i, _vp, _vp, _i64, _i, Dropout, _vp]),
     "mmfm_cast_f32_to_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "mmfm_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "mmfm_r2_series": (C.c_int, [_vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _i, _i, _i, _vp, _vp]),
+    "mmfm_bits_per_spike_workspace": (C.c_int64, [_i64, _i]),
+    "mmfm_bits_per_spike": (C.c_int, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

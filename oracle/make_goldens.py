@@ -596,13 +596,45 @@ def fx_multisession_curve():
                                               final_norm={k: float(v.double().norm()) for k, v in model.state_dict().items()}))
 
 
+def fx_eval_metrics():
+    """The reference's own bits_per_spike / neg_log_likelihood (utils/eval_utils.py:1051-1119) on seeded rate / spike arrays.
+    eval_utils imports torcheval (absent) through utils.metric_utils at module load: a placeholder module satisfies the import;
+    nothing of it runs in these two functions."""
+    import datasets
+    if not hasattr(datasets, "list_datasets"):
+        datasets.list_datasets = lambda *a, **k: []
+    te, tem = types.ModuleType("torcheval"), types.ModuleType("torcheval.metrics")
+    tem.R2Score = type("R2Score", (), {"__init__": lambda self, *a, **k: None})
+    te.metrics = tem
+    sys.modules.setdefault("torcheval", te)
+    sys.modules.setdefault("torcheval.metrics", tem)
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    import matplotlib
+    matplotlib.use("Agg")
+    from utils.eval_utils import bits_per_spike, neg_log_likelihood
+    rng = np.random.default_rng(11)
+    arrs, cases = {}, []
+    for i, (B, T, N, scale) in enumerate([(3, 5, 4, 0.3), (8, 100, 50, 0.3), (4, 20, 7, 2.0)]):
+        spikes = rng.poisson(scale, (B, T, N)).astype(np.float64)
+        rates = np.exp(rng.standard_normal((B, T, N)) * 0.5 + np.log(scale))
+        if i == 2:
+            rates[0, 0, 0] = 0.0                      # the zero-rate replacement path (1e-9)
+            spikes[:, :, 3] = 0.0                     # a silent neuron: null rate 0 -> 1e-9
+        arrs[f"c{i}/rates"], arrs[f"c{i}/spikes"] = rates.astype(np.float32), spikes.astype(np.float32)
+        r32, s32 = arrs[f"c{i}/rates"].astype(np.float64), arrs[f"c{i}/spikes"].astype(np.float64)
+        cases.append(dict(id=i, bps=float(bits_per_spike(r32.copy(), s32)), nll=float(neg_log_likelihood(r32.copy(), s32))))
+        print("   ", cases[-1])
+    arrs["meta"] = np.frombuffer(json.dumps(dict(cases=cases)).encode(), dtype=np.uint8)
+    save_npz("eval_metrics.npz", **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in [("init_order", fx_init_order), ("tiny_fwd_bwd", fx_tiny_fwd_bwd),
                      ("default_scalars", fx_default_scalars), ("masker_bits", fx_masker_bits),
                      ("mask_index_ops", fx_mask_index_ops), ("sched_adamw", fx_sched_adamw),
-                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("multisession_curve", fx_multisession_curve), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate)]:
+                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("multisession_curve", fx_multisession_curve), ("eval_metrics", fx_eval_metrics), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate)]:
         if only and name not in only:
             continue
         print(f"[{name}]")

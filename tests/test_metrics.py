@@ -1,0 +1,66 @@
+"""evaluation metrics.  CPU: the numpy oracle vs the fixture produced by the reference's own
+bits_per_spike / neg_log_likelihood, and vs scikit-learn for R^2 (torcheval absent: see oracle/metrics_oracle.py).
+GPU: mmfm_bits_per_spike / mmfm_r2_series through the C-ABI vs the oracle and the fixture."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_npz
+from oracle import metrics_oracle as MO
+
+
+def test_bits_per_spike_oracle_vs_reference_fixture():
+    z, meta = load_npz("eval_metrics.npz")
+    for c in meta["cases"]:
+        r, s = z[f"c{c['id']}/rates"].astype(np.float64), z[f"c{c['id']}/spikes"].astype(np.float64)
+        assert MO.neg_log_likelihood(r, s) == pytest.approx(c["nll"], rel=1e-12)
+        assert MO.bits_per_spike(r, s) == pytest.approx(c["bps"], rel=1e-12)
+
+
+def test_r2_oracle_vs_sklearn():
+    from sklearn.metrics import r2_score
+    rng = np.random.default_rng(0)
+    gt, pred = rng.standard_normal((6, 40, 5)), rng.standard_normal((6, 40, 5))
+    got = MO.r2_series(gt, pred)
+    for g in range(6):
+        for c in range(5):
+            assert got[g, c] == pytest.approx(r2_score(gt[g, :, c], pred[g, :, c]), rel=1e-12)
+    gt[2, :, 1] = 3.0                                        # constant series -> invalid, masked out of the trial average
+    vals = MO.r2_series(gt, pred)
+    assert not np.isfinite(vals[2, 1])
+    expect = np.mean([np.mean([v for v in row if np.isfinite(v)]) for row in vals])
+    assert MO.trial_avg_r2(gt, pred) == pytest.approx(expect, rel=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_bits_per_spike_vs_reference_fixture():
+    from multi_modal_foundation_model_amd.metrics import bits_per_spike
+    z, meta = load_npz("eval_metrics.npz")
+    for c in meta["cases"]:
+        r, s = torch.from_numpy(z[f"c{c['id']}/rates"]).cuda(), torch.from_numpy(z[f"c{c['id']}/spikes"]).cuda()
+        assert bits_per_spike(r, s) == pytest.approx(c["bps"], rel=2e-5, abs=1e-6)      # fp64 sums, fp32 result
+    # eval-sized problem (B = 512 trials x 100 bins x 668 neurons) against the oracle
+    g = torch.Generator().manual_seed(1)
+    s = torch.poisson(torch.full((512, 100, 668), 0.3), generator=g)
+    r = torch.exp(torch.randn(512, 100, 668, generator=g) * 0.3 - 1.2)
+    assert bits_per_spike(r.cuda(), s.cuda()) == pytest.approx(MO.bits_per_spike(r.numpy(), s.numpy()), rel=2e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_r2_series_and_metrics_list():
+    from multi_modal_foundation_model_amd.metrics import r2_series, trial_avg_r2
+    from utils.utils import metrics_list
+    g = torch.Generator().manual_seed(2)
+    base_gt, base_pr = torch.randn(40, 100, 50, generator=g), torch.randn(40, 100, 50, generator=g)
+    base_gt[3, :, 7] = 0.25                                  # a constant series
+    # the trainer's view: [B, T, 50].transpose(-1, 0) = [50, T, B], non-contiguous (trainer/base.py:252-256)
+    gt, pr = base_gt.cuda().transpose(-1, 0), base_pr.cuda().transpose(-1, 0)
+    got = r2_series(gt, pr).cpu().numpy()
+    ref = MO.r2_series(gt.cpu().numpy(), pr.cpu().numpy())
+    fin = np.isfinite(ref)
+    assert (np.isfinite(got) == fin).all()
+    np.testing.assert_allclose(got[fin], ref[fin], rtol=1e-5, atol=1e-6)
+    want = MO.trial_avg_r2(gt.cpu().numpy(), pr.cpu().numpy())
+    assert trial_avg_r2(gt, pr) == pytest.approx(want, rel=1e-5)
+    assert metrics_list(gt, pr, metrics=["r2"])["r2"] == pytest.approx(want, rel=1e-5)       # device path of the API mirror
+    assert metrics_list(gt.cpu(), pr.cpu(), metrics=["r2"])["r2"] == pytest.approx(want, rel=1e-9)   # host path unchanged
