@@ -110,21 +110,31 @@ __device__ __forceinline__ void wave_lds_fence() {
 // ============================================================================ forward
 // element-wise part of one 32-key x 32-query tile: online softmax + dropout.  FULL = every (q, key) of the tile is
 // valid and allowed (no padding, no causal/sep flags): the mask logic disappears.
+// G = number of 8-key groups of the tile that hold any valid key (accumulator registers 4g..4g+3 are keys 8g + 4*kh + 0..3):
+// the last key tile of a 200-token head has one (keys 192..199), so three quarters of its element-wise work is skipped.
 template <bool FULL, bool DROP>
 __device__ __forceinline__ bool fwd_tile(const f32x16& st, float c2, float& m_run, float& l_run, float& alpha, float (&pd)[16], int q,
-                                         int Lq, int Lk, int kt, int kh, const MaskCtx& mk, const Drop16& dp, uint32_t pair_base) {
+                                         int Lq, int Lk, int kt, int kh, const MaskCtx& mk, const Drop16& dp, uint32_t pair_base, int G) {
     uint32_t okm = 0xffffu;
     float mx = -INFINITY;
     if (FULL) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[r]);
+        for (int g = 0; g < 4; ++g)
+            if (g < G) {
+#pragma unroll
+                for (int r = 4 * g; r < 4 * g + 4; ++r) mx = fmaxf(mx, st[r]);
+            }
     } else {
         okm = 0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = kt * 32 + mrow(r, kh);
-            if ((key < Lk) && (q < Lq) && mk.allowed(q, key)) { okm |= 1u << r; mx = fmaxf(mx, st[r]); }
-        }
+        for (int g = 0; g < 4; ++g)
+            if (g < G) {
+#pragma unroll
+                for (int r = 4 * g; r < 4 * g + 4; ++r) {
+                    const int key = kt * 32 + mrow(r, kh);
+                    if ((key < Lk) && (q < Lq) && mk.allowed(q, key)) { okm |= 1u << r; mx = fmaxf(mx, st[r]); }
+                }
+            }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx * c2);                      // c2 > 0
@@ -133,21 +143,29 @@ __device__ __forceinline__ bool fwd_tile(const f32x16& st, float c2, float& m_ru
     alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_use);
     float ps = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-        float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -m_use));
-        float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r + 1], c2, -m_use));
-        if (!FULL) {
-            p0 = (okm >> r) & 1 ? p0 : 0.f;
-            p1 = (okm >> (r + 1)) & 1 ? p1 : 0.f;
+    for (int g = 0; g < 4; ++g) {
+        if (g < G) {
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 4; r += 2) {
+                float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -m_use));
+                float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r + 1], c2, -m_use));
+                if (!FULL) {
+                    p0 = (okm >> r) & 1 ? p0 : 0.f;
+                    p1 = (okm >> (r + 1)) & 1 ? p1 : 0.f;
+                }
+                ps += p0 + p1;
+                if (DROP) {
+                    const uint32_t hsh = dp.hash(pair_base + (uint32_t)((kt * 32 + mrow(r, kh)) >> 1));
+                    p0 = (hsh & 0xffffu) >= dp.t16 ? p0 * dp.scale : 0.f;
+                    p1 = (hsh >> 16) >= dp.t16 ? p1 * dp.scale : 0.f;
+                }
+                pd[r] = p0;
+                pd[r + 1] = p1;
+            }
+        } else {
+#pragma unroll
+            for (int r = 4 * g; r < 4 * g + 4; ++r) pd[r] = 0.f;
         }
-        ps += p0 + p1;
-        if (DROP) {
-            const uint32_t hsh = dp.hash(pair_base + (uint32_t)((kt * 32 + mrow(r, kh)) >> 1));
-            p0 = (hsh & 0xffffu) >= dp.t16 ? p0 * dp.scale : 0.f;
-            p1 = (hsh >> 16) >= dp.t16 ? p1 * dp.scale : 0.f;
-        }
-        pd[r] = p0;
-        pd[r + 1] = p1;
     }
     l_run = l_run * alpha + ps;
     m_run = m_new;
@@ -207,7 +225,6 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
 
     for (int qt = wave; qt < nqt; qt += NW) {
         const int q0 = qt * 32, q = q0 + l31;
-        const bool qfull = nomask && (q0 + 32 <= Lq);
         // 32-bit pair index (wraps identically in the forward and both backward phases for very large batches)
         const uint32_t pair_base = ((uint32_t)blockIdx.x * (uint32_t)Lq + (uint32_t)q) * (uint32_t)LkH;
         bf16x8v qf[KS];
@@ -241,12 +258,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
             if (kt + 1 < nkt) st_next = score(kt + 1);
             float alpha, pd[16];
             bool live;
-            if (qfull && kt * 32 + 32 <= Lk)
-                live = dp.on ? fwd_tile<true, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base)
-                             : fwd_tile<true, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base);
+            // valid keys of this tile in groups of 8; with no mask in play and whole groups the mask-free code runs on
+            // the valid groups only.  Lanes of queries >= Lq then carry finite garbage that is never stored (their keys'
+            // zero-padded rows give finite scores) - the softmax of a query is lane-local.
+            const int nk = min(32, Lk - kt * 32), G = (nk + 7) >> 3;
+            if (nomask && (nk & 7) == 0)
+                live = dp.on ? fwd_tile<true, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G)
+                             : fwd_tile<true, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G);
             else
-                live = dp.on ? fwd_tile<false, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base)
-                             : fwd_tile<false, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base);
+                live = dp.on ? fwd_tile<false, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G)
+                             : fwd_tile<false, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G);
             if (!live) continue;
             const bf16x8v pf0 = pack8(pd), pf1 = pack8(pd + 8);
             const bool rescale = !__all(alpha == 1.f);
@@ -257,7 +278,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
                     for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
                 }
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, VRS, kt * 32, i * 32, lane), pf0, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, VRS, kt * 32 + 16, i * 32, lane), pf1, acc[i], 0, 0, 0);
+                if (G > 2) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, VRS, kt * 32 + 16, i * 32, lane), pf1, acc[i], 0, 0, 0);
             }
         }
         const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -287,28 +308,44 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
 
 // ============================================================================ backward
 // Phase A, one half-tile (accumulator rows 8*s2 .. 8*s2+7 = 8 queries, lane = key): P~ (dropped, scaled) and dS.
+// G = number of 8-query groups of the tile holding any valid query (registers 4g..4g+3 = queries 8g + 4*kh + 0..3); this half
+// tile covers groups 2*s2 and 2*s2 + 1.  The caller skips a half tile with no valid group.
 template <bool FULL, bool DROP>
 __device__ __forceinline__ void bwdA_half(const f32x16& s, const f32x16& dpv, int s2, float (&pd)[8], float (&ds)[8], float c2, float scale,
                                           const float* lse2, const float* dlt, int qt, int key, int kh, int Lq, int Lk, const MaskCtx& mk,
-                                          const Drop16& dp, uint32_t pbase, int LkH) {
+                                          const Drop16& dp, uint32_t pbase, int LkH, int G) {
     // One hash decides a PAIR of keys (even key: low 16 bits, odd key: high 16 bits).  Here the lane is the key, so the two
     // keys of a pair sit in neighbouring lanes and would both evaluate the same hash: instead the even lane hashes the
     // half-tile's first four queries, the odd lane its last four, and a quad-permute DPP move swaps them (12 -> 7.5 VALU
-    // per decision; this kernel is VALU-issue bound).
+    // per decision; this kernel is VALU-issue bound).  With only the first group valid every lane hashes its own four.
+    const bool both = G > 2 * s2 + 1;
     uint32_t hq[8];
     if (DROP) {
         const int par = key & 1;
+        if (both) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int qmine = qt * 32 + e + 8 * (2 * s2 + par) + 4 * kh;          // = mrow(8*s2 + e + 4*par, kh)
-            const uint32_t mine = dp.hash((pbase + (uint32_t)qmine) * (uint32_t)LkH + (uint32_t)(key >> 1));
-            const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-            hq[e] = par ? other : mine;          // query e      (hashed by the even lane)
-            hq[e + 4] = par ? mine : other;      // query e + 4  (hashed by the odd lane)
+            for (int e = 0; e < 4; ++e) {
+                const int qmine = qt * 32 + e + 8 * (2 * s2 + par) + 4 * kh;          // = mrow(8*s2 + e + 4*par, kh)
+                const uint32_t mine = dp.hash((pbase + (uint32_t)qmine) * (uint32_t)LkH + (uint32_t)(key >> 1));
+                const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+                hq[e] = par ? other : mine;          // query e      (hashed by the even lane)
+                hq[e + 4] = par ? mine : other;      // query e + 4  (hashed by the odd lane)
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                hq[e] = dp.hash((pbase + (uint32_t)(qt * 32 + e + 16 * s2 + 4 * kh)) * (uint32_t)LkH + (uint32_t)(key >> 1));
+                hq[e + 4] = 0u;
+            }
         }
     }
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
+        if (e >= 4 && !both) {
+            pd[e] = 0.f;
+            ds[e] = 0.f;
+            continue;
+        }
         const int r = 8 * s2 + e;
         const int q = qt * 32 + mrow(r, kh);
         float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -lse2[q]));
@@ -506,16 +543,17 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
             const f32x16 s = s_next, dpv = dp_next;
             if (qt + 1 < nqt) scoresA(qt + 1);
             const bool full = nomask && (kt * 32 + 32 <= Lk) && (qt * 32 + 32 <= Lq);
+            constexpr int GRP = 4;
             // two half-tiles of 8 accumulator rows each: softmax/dropout algebra, pack to bf16, feed the MFMAs
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 float pd[8], ds[8];
                 if (full) {
-                    if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
-                    else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
+                    if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                    else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
                 } else {
-                    if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
-                    else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
+                    if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                    else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
                 }
                 const bf16x8v pf = pack8(pd), sf = pack8(ds);
 #pragma unroll
@@ -735,17 +773,23 @@ __global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_
                 if (!PIPE) scoresA(qt);
                 const f32x16 s = s_next, dpv = dp_next;
                 if (PIPE && qt + 1 < nqt) scoresA(qt + 1);
-                const bool full = nomask && (kt * 32 + 32 <= Lk) && (qt * 32 + 32 <= Lq);
+                // valid queries of this tile in groups of 8 (accumulator registers 4g..4g+3): the last query tile of a
+                // 200-token head has one group, so 3/4 of its element-wise work and half of its MFMAs are skipped.  With no
+                // mask in play and whole groups the mask-free code runs: lanes of keys >= Lk then carry finite garbage that
+                // only reaches dK/dV rows that are never stored, and dQ through K^T columns that are zero.
+                const int nq = min(32, Lq - qt * 32), GRP = (nq + 7) >> 3;
+                const bool full = nomask && (nq & 7) == 0;
                 char* slot = stg + ((qt & 1) * CW + wave) * TILE + l31 * TS;
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
+                    if (2 * s2 >= GRP) continue;
                     float pd[8], ds[8];
                     if (full) {
-                        if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
-                        else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
+                        if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                        else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
                     } else {
-                        if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
-                        else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH);
+                        if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                        else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
                     }
                     const bf16x8v pf = pack8(pd), sf = pack8(ds);
                     // dS^T[key = lane][q]: elements 0..3 are queries 16*s2 + 4*kh + 0..3, elements 4..7 the same + 8
