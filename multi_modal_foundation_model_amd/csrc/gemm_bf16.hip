@@ -147,6 +147,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // Epilogue of one output tile (see the comment inside).  `smem` is the workgroup's operand LDS, free at this point.
+// 8 bf16 of an epilogue chunk: one 16-B access, or - rows only 8-B aligned / ragged last chunk (N % 8 == 4, e.g. the
+// 668-neuron head and token-embedding shapes) - two 8-B halves of which the second exists only if `hi`
+__device__ __forceinline__ uint4 ldg8(const uint16_t* p, bool a16, bool hi) {
+    if (a16) return *reinterpret_cast<const uint4*>(p);
+    const uint2 a = *reinterpret_cast<const uint2*>(p);
+    const uint2 b = hi ? *reinterpret_cast<const uint2*>(p + 4) : make_uint2(0u, 0u);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+__device__ __forceinline__ void stg8(uint16_t* p, uint4 v, bool a16, bool hi) {
+    if (a16) { *reinterpret_cast<uint4*>(p) = v; return; }
+    *reinterpret_cast<uint2*>(p) = make_uint2(v.x, v.y);
+    if (hi) *reinterpret_cast<uint2*>(p + 4) = make_uint2(v.z, v.w);
+}
+
 template <typename TO>
 __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int z, int vec_epi,
                                               int t, int wm, int wn, int kh, int l31) {
@@ -177,7 +191,8 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
             for (int c = 0; c < 4; ++c) {
                 const int chunk = t + 256 * c, row = chunk >> 4, col = (chunk & 15) * 8;
                 const int m = m0 + half * 64 + row, n = n0 + col;
-                if (m >= d.M || n >= d.N) continue;          // N % 8 == 0 on this path: chunks are all-in or all-out
+                if (m >= d.M || n >= d.N) continue;          // chunks are all-in, all-out or (half mode) 4 columns in
+                const bool a16 = !(vec_epi & 2), hi = n + 8 <= d.N;
                 float v[8];
                 const float4 s0 = *reinterpret_cast<const float4*>(stage + row * SLDW + col);
                 const float4 s1 = *reinterpret_cast<const float4*>(stage + row * SLDW + col + 4);
@@ -186,18 +201,19 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
                 if (split || sizeof(TO) == 4) {
                     if (!split && d.bias) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += d.bias[n + e];
+                        for (int e = 0; e < 8; ++e) v[e] += (e < 4 || hi) ? d.bias[n + e] : 0.f;
                     }
                     float* dst = (split ? Cf : reinterpret_cast<float*>(d.C)) + off;
                     *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    if (hi) *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
                     continue;
                 }
                 if (d.bias) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n), b1 = *reinterpret_cast<const float4*>(d.bias + n + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n);
+                    const float4 b1 = hi ? *reinterpret_cast<const float4*>(d.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                 }
-                if (d.pre_out) *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.pre_out) + off) = __builtin_bit_cast(uint4, pack8f(v));
+                if (d.pre_out) stg8(reinterpret_cast<uint16_t*>(d.pre_out) + off, __builtin_bit_cast(uint4, pack8f(v)), a16, hi);
                 if (d.act == 1) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
@@ -207,7 +223,7 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
                 }
                 if (d.gradmul_pre) {
                     float u[8];
-                    unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(d.gradmul_pre) + off), u);
+                    unpack8(ldg8(reinterpret_cast<const uint16_t*>(d.gradmul_pre) + off, a16, hi), u);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= (d.act == 3) ? gelu_erf_grad(u[e]) : softsign_grad(u[e]) * d.act_scale;
                 }
@@ -218,11 +234,11 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
                 }
                 if (d.residual) {
                     float u[8];
-                    unpack8(*reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(d.residual) + (size_t)m * d.ldr + n), u);
+                    unpack8(ldg8(reinterpret_cast<const uint16_t*>(d.residual) + (size_t)m * d.ldr + n, a16, hi), u);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += u[e];
                 }
-                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(d.C) + off) = __builtin_bit_cast(uint4, pack8f(v));
+                stg8(reinterpret_cast<uint16_t*>(d.C) + off, __builtin_bit_cast(uint4, pack8f(v)), a16, hi);
             }
         }
         return;
@@ -391,8 +407,14 @@ int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     dim3 grid(f32out ? std::min(total_items, 256 * wg_per_cu) : total_items), block(NTHREADS);   // persistent: 3 resident workgroups per CU
     // vector epilogue needs 16-B aligned 8-column chunks of every tensor it touches
     auto al16 = [](const void* p) { return p == nullptr || (uintptr_t)p % 16 == 0; };
-    const int vec = (d.N % 8 == 0) && (d.ldc % 8 == 0) && al16(d.C) && al16(d.pre_out) && al16(d.gradmul_pre) && al16(d.bias) &&
-                    (!d.residual || (d.ldr % 8 == 0 && al16(d.residual))) && (!d.splits || d.splits == 1 || d.slab_stride % 4 == 0);
+    const int vec8 = (d.N % 8 == 0) && (d.ldc % 8 == 0) && al16(d.C) && al16(d.pre_out) && al16(d.gradmul_pre) && al16(d.bias) &&
+                     (!d.residual || (d.ldr % 8 == 0 && al16(d.residual))) && (!d.splits || d.splits == 1 || d.slab_stride % 4 == 0);
+    // half mode: 4-column granularity (N = 668): bf16 rows are 8-B aligned, fp32 rows 16-B aligned
+    auto al8 = [](const void* p) { return p == nullptr || (uintptr_t)p % 8 == 0; };
+    const bool f32c = d.c_f32 || d.splits > 1;
+    const int vec4 = (d.N % 4 == 0) && (d.ldc % 4 == 0) && (f32c ? al16(d.C) : al8(d.C)) && al8(d.pre_out) && al8(d.gradmul_pre) && al16(d.bias) &&
+                     (!d.residual || (d.ldr % 4 == 0 && al8(d.residual))) && (!d.splits || d.splits == 1 || d.slab_stride % 4 == 0);
+    const int vec = vec8 ? 1 : (vec4 ? 3 : 0);
     static const int abl = [] { const char* e = getenv("MMFM_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     const int vecf = vec | (abl << 8);
 #define LAUNCH2(ARC, BRC, BKV)                                                                                    \
