@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--dtype", default=os.environ.get("MMFM_DTYPE", "bf16"), choices=["fp32", "bf16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-profile", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-steps", type=int, default=12, help="CPU-baseline steps at B=16 (~1 s each on 16 threads: a 10-15 s bounded sample)")
     return ap.parse_args()
 
 

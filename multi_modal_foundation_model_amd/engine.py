@@ -267,13 +267,14 @@ class Engine:
 
     # ------------------------------------------------------------------ plan construction
     def _dw_split(self, M, N, R):
-        """Split-K factor for a dW GEMM ([M,N] output, reduction over R tokens): just enough splits to put
-        ~2 workgroups on every CU (the slab reduction costs S x M x N x 4 bytes of traffic, so no more)."""
+        """Split-K factor for a dW GEMM ([M,N] output, reduction over R tokens): tiles x splits fills the persistent
+        grid of the bf16 kernel (256 CUs x 3 workgroups) exactly once - measured against 512 items at B = 1024: qkv dW
+        182 -> 155 us, token-embed dW 639 -> 508 us - capped at 128 slabs (the slab reduction costs S x M x N x 4 bytes)."""
         tiles = -(-M // 128) * -(-N // 128)
         if R <= 8192:                     # launch-bound regime (reference batch 16 -> R = 3200): <= 15 slabs = one-stage reduce
             S = max(1, min(R // 256, 15))
         else:
-            S = max(1, min(R // 512, -(-512 // tiles)))
+            S = max(1, min(R // 512, max(1, 768 // tiles), 128))
         kchunk = _align(-(-R // S), 64)          # multiple of both kernels' BK (32 fp32, 64 bf16)
         return -(-R // kchunk), kchunk
 

@@ -36,7 +36,8 @@ for name, M, N, K in [("qkv", R, 768, 256), ("proj", R, 256, 256), ("up", R, 512
     print(f"NN {name:5s} {M:7d} {K:5d} {N:7d} {ms*1e3:8.1f} {2*M*N*K/ms/1e9:7.1f} {by/ms/1e6:7.0f}")
     # dW[N,K] = dY^T X, split-K like the engine
     tiles = -(-N // 128) * -(-K // 128)
-    S = max(1, min(M // 512, -(-512 // tiles)))
+    SLOTS = int(os.environ.get("DW_SLOTS", "512"))
+    S = max(1, min(M // 512, -(-SLOTS // tiles) if SLOTS == 512 else max(1, SLOTS // tiles)))
     kchunk = (-(-M // S) + 63) // 64 * 64
     S = -(-M // kchunk)
     slabs, dw = torch.empty(S, N, K, device="cuda"), torch.empty(N, K, device="cuda")
