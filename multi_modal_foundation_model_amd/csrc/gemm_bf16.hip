@@ -155,7 +155,13 @@ __device__ __forceinline__ uint4 ldg8(const uint16_t* p, bool a16, bool hi) {
     const uint2 b = hi ? *reinterpret_cast<const uint2*>(p + 4) : make_uint2(0u, 0u);
     return make_uint4(a.x, a.y, b.x, b.y);
 }
-__device__ __forceinline__ void stg8(uint16_t* p, uint4 v, bool a16, bool hi) {
+__device__ __forceinline__ void stg8(uint16_t* p, uint4 v, bool a16, bool hi, bool nt) {
+    if (nt) {            // streaming store (see common.h): the tile is not read again by this kernel
+        if (a16) { st_stream(reinterpret_cast<uint4*>(p), v); return; }
+        st_stream(reinterpret_cast<uint2*>(p), make_uint2(v.x, v.y));
+        if (hi) st_stream(reinterpret_cast<uint2*>(p + 4), make_uint2(v.z, v.w));
+        return;
+    }
     if (a16) { *reinterpret_cast<uint4*>(p) = v; return; }
     *reinterpret_cast<uint2*>(p) = make_uint2(v.x, v.y);
     if (hi) *reinterpret_cast<uint2*>(p + 4) = make_uint2(v.z, v.w);
@@ -204,8 +210,13 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
                         for (int e = 0; e < 8; ++e) v[e] += (e < 4 || hi) ? d.bias[n + e] : 0.f;
                     }
                     float* dst = (split ? Cf : reinterpret_cast<float*>(d.C)) + off;
-                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    if (hi) *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    if (vec_epi & 16384) {
+                        st_stream(reinterpret_cast<float4*>(dst), make_float4(v[0], v[1], v[2], v[3]));
+                        if (hi) st_stream(reinterpret_cast<float4*>(dst + 4), make_float4(v[4], v[5], v[6], v[7]));
+                    } else {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        if (hi) *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
                     continue;
                 }
                 if (d.bias) {
@@ -213,7 +224,7 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
                     const float4 b1 = hi ? *reinterpret_cast<const float4*>(d.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
                     v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                 }
-                if (d.pre_out) stg8(reinterpret_cast<uint16_t*>(d.pre_out) + off, __builtin_bit_cast(uint4, pack8f(v)), a16, hi);
+                if (d.pre_out) stg8(reinterpret_cast<uint16_t*>(d.pre_out) + off, __builtin_bit_cast(uint4, pack8f(v)), a16, hi, (vec_epi & 8192) != 0);
                 if (d.act == 1) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
@@ -238,7 +249,7 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += u[e];
                 }
-                stg8(reinterpret_cast<uint16_t*>(d.C) + off, __builtin_bit_cast(uint4, pack8f(v)), a16, hi);
+                stg8(reinterpret_cast<uint16_t*>(d.C) + off, __builtin_bit_cast(uint4, pack8f(v)), a16, hi, (vec_epi & 4096) != 0);
             }
         }
         return;
@@ -416,7 +427,9 @@ int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
                      (!d.residual || (d.ldr % 4 == 0 && al8(d.residual))) && (!d.splits || d.splits == 1 || d.slab_stride % 4 == 0);
     const int vec = vec8 ? 1 : (vec4 ? 3 : 0);
     static const int abl = [] { const char* e = getenv("MMFM_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-    const int vecf = vec | (abl << 8);
+    // MMFM_GEMM_NT: bit 0 = bf16 output C, bit 1 = saved pre-activation, bit 2 = fp32 output / split-K slabs stored non-temporally
+    static const int nt_env = [] { const char* e = getenv("MMFM_GEMM_NT"); return e ? atoi(e) : 3; }();
+    const int vecf = vec | (abl << 8) | ((nt_env & 1) ? 4096 : 0) | ((nt_env & 2) ? 8192 : 0) | ((nt_env & 4) ? 16384 : 0);
 #define LAUNCH2(ARC, BRC, BKV)                                                                                    \
     if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float, BKV>), grid, block, 0, st, d, aA, aB, vecf, total_items);  \
     else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t, BKV>), grid, block, 0, st, d, aA, aB, vecf, total_items);
