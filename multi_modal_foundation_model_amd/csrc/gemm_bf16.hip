@@ -149,7 +149,8 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Epilogue of one output tile (see the comment inside).  `smem` is the workgroup's operand LDS, free at this point.
 // 8 bf16 of an epilogue chunk: one 16-B access, or - rows only 8-B aligned / ragged last chunk (N % 8 == 4, e.g. the
 // 668-neuron head and token-embedding shapes) - two 8-B halves of which the second exists only if `hi`
-__device__ __forceinline__ uint4 ldg8(const uint16_t* p, bool a16, bool hi) {
+__device__ __forceinline__ uint4 ldg8(const uint16_t* p, bool a16, bool hi, bool nt) {
+    if (a16 && nt) return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const mmfm_u32x4*>(p)));
     if (a16) return *reinterpret_cast<const uint4*>(p);
     const uint2 a = *reinterpret_cast<const uint2*>(p);
     const uint2 b = hi ? *reinterpret_cast<const uint2*>(p + 4) : make_uint2(0u, 0u);
@@ -234,7 +235,7 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
                 }
                 if (d.gradmul_pre) {
                     float u[8];
-                    unpack8(ldg8(reinterpret_cast<const uint16_t*>(d.gradmul_pre) + off, a16, hi), u);
+                    unpack8(ldg8(reinterpret_cast<const uint16_t*>(d.gradmul_pre) + off, a16, hi, (vec_epi & 32768) != 0), u);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= (d.act == 3) ? gelu_erf_grad(u[e]) : softsign_grad(u[e]) * d.act_scale;
                 }
@@ -245,7 +246,7 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
                 }
                 if (d.residual) {
                     float u[8];
-                    unpack8(ldg8(reinterpret_cast<const uint16_t*>(d.residual) + (size_t)m * d.ldr + n, a16, hi), u);
+                    unpack8(ldg8(reinterpret_cast<const uint16_t*>(d.residual) + (size_t)m * d.ldr + n, a16, hi, (vec_epi & 32768) != 0), u);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += u[e];
                 }
@@ -427,9 +428,10 @@ int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
                      (!d.residual || (d.ldr % 4 == 0 && al8(d.residual))) && (!d.splits || d.splits == 1 || d.slab_stride % 4 == 0);
     const int vec = vec8 ? 1 : (vec4 ? 3 : 0);
     static const int abl = [] { const char* e = getenv("MMFM_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
-    // MMFM_GEMM_NT: bit 0 = bf16 output C, bit 1 = saved pre-activation, bit 2 = fp32 output / split-K slabs stored non-temporally
+    // MMFM_GEMM_NT: bit 0 = bf16 output C, bit 1 = saved pre-activation, bit 2 = fp32 output / split-K slabs stored non-temporally, bit 3 = residual / saved
+    // pre-activation LOADED non-temporally
     static const int nt_env = [] { const char* e = getenv("MMFM_GEMM_NT"); return e ? atoi(e) : 3; }();
-    const int vecf = vec | (abl << 8) | ((nt_env & 1) ? 4096 : 0) | ((nt_env & 2) ? 8192 : 0) | ((nt_env & 4) ? 16384 : 0);
+    const int vecf = vec | (abl << 8) | ((nt_env & 1) ? 4096 : 0) | ((nt_env & 2) ? 8192 : 0) | ((nt_env & 4) ? 16384 : 0) | ((nt_env & 8) ? 32768 : 0);
 #define LAUNCH2(ARC, BRC, BKV)                                                                                    \
     if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float, BKV>), grid, block, 0, st, d, aA, aB, vecf, total_items);  \
     else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t, BKV>), grid, block, 0, st, d, aA, aB, vecf, total_items);
