@@ -228,6 +228,12 @@ int mmfm_r2_series(const float* gt, const int64_t* gt_strides, const float* pred
 int64_t mmfm_bits_per_spike_workspace(int64_t R, int N);
 int mmfm_bits_per_spike(const float* rates, const float* spikes, int64_t R, int N, float* out,
                         void* workspace, int64_t workspace_bytes, mmfm_stream stream);
+/* utils/eval_utils.py:846-851 (spiking_activity_recon_eval: bits_per_spike on each neuron's own slice, N host calls
+ * upstream): out[n] = bits per spike of neuron n against ITS mean rate, all N in one pass.  A silent neuron gives
+ * inf / nan like upstream (which then records NaN). */
+int64_t mmfm_bits_per_spike_neurons_workspace(int64_t R, int N);
+int mmfm_bits_per_spike_neurons(const float* rates, const float* spikes, int64_t R, int N, float* out,
+                                void* workspace, int64_t workspace_bytes, mmfm_stream stream);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,8 @@ _PROTOS = {
     "mmfm_r2_series": (C.c_int, [_vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _i, _i, _i, _vp, _vp]),
     "mmfm_bits_per_spike_workspace": (C.c_int64, [_i64, _i]),
     "mmfm_bits_per_spike": (C.c_int, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),
+    "mmfm_bits_per_spike_neurons_workspace": (C.c_int64, [_i64, _i]),
+    "mmfm_bits_per_spike_neurons": (C.c_int, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),
 }
 
 _lib = None

@@ -78,6 +78,48 @@ __global__ void bps_final_kernel(const double* __restrict__ part, int nblk, floa
     out[3] = (float)c;
 }
 
+// per-neuron bits per spike (spiking_activity_recon_eval, utils/eval_utils.py:846-851: bits_per_spike on one neuron's
+// [trials, bins, 1] slice, N host calls upstream).  The log n! terms of the model and the null likelihood cancel:
+//   nll_null - nll_model = R*mu - log(mu) * S - A,   A = sum_t (r - s log r),  S = sum_t s,  mu = S / R  (0 -> 1e-9).
+// Stage 1: each block owns 64 columns x a row chunk and writes fp64 partials [chunk][2][N]; stage 2 sums the chunks in
+// order and finishes the formula.
+__global__ __launch_bounds__(256) void bpsn_partial_kernel(const float* __restrict__ rates, const float* __restrict__ spikes, int64_t R, int N,
+                                                           int rows_per_chunk, double* __restrict__ part) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + cl;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk, r1 = min(R, r0 + rows_per_chunk);
+    double a = 0.0, sm = 0.0;
+    if (col < N)
+        for (int64_t r = r0 + rl; r < r1; r += 4) {
+            const double s = (double)spikes[r * N + col];
+            double rt = (double)rates[r * N + col];
+            if (rt == 0.0) rt = 1e-9;
+            a += rt - s * log(rt);
+            sm += s;
+        }
+    red[0][rl][cl] = a;
+    red[1][rl][cl] = sm;
+    __syncthreads();
+    if (rl == 0 && col < N) {
+        double* o = part + (size_t)blockIdx.y * 2 * N;
+        o[col] = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        o[N + col] = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+    }
+}
+
+__global__ __launch_bounds__(256) void bpsn_final_kernel(const double* __restrict__ part, int nchunk, int64_t R, int N, float* __restrict__ out) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= N) return;
+    double a = 0.0, sm = 0.0;
+    for (int c = 0; c < nchunk; ++c) { a += part[(size_t)c * 2 * N + col]; sm += part[(size_t)c * 2 * N + N + col]; }
+    double mu = sm / (double)R;
+    if (mu == 0.0) mu = 1e-9;
+    out[col] = (float)(((double)R * mu - log(mu) * sm - a) / sm / 0.6931471805599453);      // S = 0 -> inf / nan like upstream
+}
+
+int bpsn_chunks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(256, R / 64)); }
+
 int bps_blocks(int64_t n) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (n + 255) / 256)); }
 
 }  // namespace
@@ -116,5 +158,20 @@ extern "C" int mmfm_bits_per_spike(const float* rates, const float* spikes, int6
     hipLaunchKernelGGL(bps_partial_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, rates, spikes, colsum, R, N, part);
     hipLaunchKernelGGL(bps_final_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, nblk, out);
     MMFM_LAUNCH_CHECK("mmfm_bits_per_spike");
+    return 0;
+}
+
+extern "C" int64_t mmfm_bits_per_spike_neurons_workspace(int64_t R, int N) { return (int64_t)bpsn_chunks(R) * 2 * N * (int64_t)sizeof(double); }
+
+extern "C" int mmfm_bits_per_spike_neurons(const float* rates, const float* spikes, int64_t R, int N, float* out, void* workspace,
+                                           int64_t workspace_bytes, mmfm_stream stream) {
+    MMFM_REQUIRE(rates && spikes && out && workspace, "mmfm_bits_per_spike_neurons: null pointer");
+    MMFM_REQUIRE(R > 0 && N > 0, "mmfm_bits_per_spike_neurons: bad shape");
+    MMFM_REQUIRE(workspace_bytes >= mmfm_bits_per_spike_neurons_workspace(R, N), "mmfm_bits_per_spike_neurons: workspace too small");
+    const int nch = bpsn_chunks(R);
+    const int rpc = (int)((R + nch - 1) / nch);
+    hipLaunchKernelGGL(bpsn_partial_kernel, dim3((N + 63) / 64, nch), dim3(256), 0, (hipStream_t)stream, rates, spikes, R, N, rpc, (double*)workspace);
+    hipLaunchKernelGGL(bpsn_final_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, nch, R, N, out);
+    MMFM_LAUNCH_CHECK("mmfm_bits_per_spike_neurons");
     return 0;
 }

@@ -5,6 +5,9 @@
 * `trial_avg_r2(gt, pred)`   - `metrics_list(..., metrics=["r2"])["r2"]`: nan/inf-masked mean over c, mean over g.
 * `bits_per_spike(rates, spikes)` - `utils/eval_utils.py:1095-1119` (NLB co-smoothing metric).
 
+* `bits_per_spike_per_neuron(rates, spikes)` - the per-neuron loop of `spiking_activity_recon_eval`
+                               (`utils/eval_utils.py:846-851`, N host calls upstream) in one pass; inf -> nan like upstream.
+
 There is no CPU path here: tensors must live on the GPU (the CPU restatement is oracle/metrics_oracle.py, test-only).
 """
 from __future__ import annotations
@@ -60,3 +63,20 @@ def bits_per_spike(rates, spikes) -> float:
     out = torch.empty(4, device=r.device, dtype=torch.float32)
     L.check(L.lib().mmfm_bits_per_spike(P(r), P(s), R, N, P(out), P(ws), ws.numel(), stream()), "mmfm_bits_per_spike")
     return float(out[0].item())
+
+
+def bits_per_spike_per_neuron(rates, spikes) -> torch.Tensor:
+    """[..., N] rates / spikes -> [N] fp32 (on the device): bits_per_spike(rates[..., [n]], spikes[..., [n]]) for every n,
+    with upstream's `if np.isinf(bps): bps = np.nan` applied (utils/eval_utils.py:846-851)."""
+    rates, spikes = torch.as_tensor(rates), torch.as_tensor(spikes)
+    _need_cuda(rates, spikes)
+    if rates.shape != spikes.shape:
+        raise AssertionError("neg_log_likelihood: Rates and spikes should be of the same shape.")
+    N = rates.shape[-1]
+    r = rates.reshape(-1, N).float().contiguous()
+    s = spikes.reshape(-1, N).float().contiguous()
+    R = r.shape[0]
+    ws = torch.empty(L.lib().mmfm_bits_per_spike_neurons_workspace(R, N), dtype=torch.uint8, device=r.device)
+    out = torch.empty(N, device=r.device, dtype=torch.float32)
+    L.check(L.lib().mmfm_bits_per_spike_neurons(P(r), P(s), R, N, P(out), P(ws), ws.numel(), stream()), "mmfm_bits_per_spike_neurons")
+    return torch.where(torch.isinf(out), torch.full_like(out, float("nan")), out)

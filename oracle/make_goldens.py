@@ -622,6 +622,9 @@ def fx_eval_metrics():
             spikes[:, :, 3] = 0.0                     # a silent neuron: null rate 0 -> 1e-9
         arrs[f"c{i}/rates"], arrs[f"c{i}/spikes"] = rates.astype(np.float32), spikes.astype(np.float32)
         r32, s32 = arrs[f"c{i}/rates"].astype(np.float64), arrs[f"c{i}/spikes"].astype(np.float64)
+        with np.errstate(divide="ignore", invalid="ignore"):      # the per-neuron loop of spiking_activity_recon_eval (eval_utils.py:846-851)
+            per = [float(bits_per_spike(r32[:, :, [n]].copy(), s32[:, :, [n]])) for n in range(N)]
+        arrs[f"c{i}/bps_per_neuron"] = np.asarray([np.nan if np.isinf(b) else b for b in per], dtype=np.float64)
         cases.append(dict(id=i, bps=float(bits_per_spike(r32.copy(), s32)), nll=float(neg_log_likelihood(r32.copy(), s32))))
         print("   ", cases[-1])
     arrs["meta"] = np.frombuffer(json.dumps(dict(cases=cases)).encode(), dtype=np.uint8)

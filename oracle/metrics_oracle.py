@@ -47,3 +47,15 @@ def r2_series(gt, pred):
 def trial_avg_r2(gt, pred):
     """utils/utils.py:109-115: for i in gt: r2 of every row of gt[i].T, invalid-masked mean; then the mean over i."""
     return float(np.mean([np.ma.masked_invalid(v).mean() for v in r2_series(gt, pred)]))
+
+
+def bits_per_spike_per_neuron(rates, spikes):
+    """spiking_activity_recon_eval's loop (utils/eval_utils.py:846-851): bits_per_spike on each neuron's [..., [n]] slice,
+    inf -> nan."""
+    rates, spikes = np.asarray(rates, dtype=np.float64), np.asarray(spikes, dtype=np.float64)
+    out = np.empty(rates.shape[-1])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        for n in range(rates.shape[-1]):
+            b = bits_per_spike(rates[..., [n]], spikes[..., [n]])
+            out[n] = np.nan if np.isinf(b) else b
+    return out

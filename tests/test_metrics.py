@@ -17,6 +17,13 @@ def test_bits_per_spike_oracle_vs_reference_fixture():
         assert MO.bits_per_spike(r, s) == pytest.approx(c["bps"], rel=1e-12)
 
 
+def test_bits_per_spike_per_neuron_oracle_vs_reference_fixture():
+    z, meta = load_npz("eval_metrics.npz")
+    for c in meta["cases"]:
+        r, s = z[f"c{c['id']}/rates"].astype(np.float64), z[f"c{c['id']}/spikes"].astype(np.float64)
+        np.testing.assert_allclose(MO.bits_per_spike_per_neuron(r, s), z[f"c{c['id']}/bps_per_neuron"], rtol=1e-12, equal_nan=True)
+
+
 def test_r2_oracle_vs_sklearn():
     from sklearn.metrics import r2_score
     rng = np.random.default_rng(0)
@@ -44,6 +51,21 @@ def test_gpu_bits_per_spike_vs_reference_fixture():
     s = torch.poisson(torch.full((512, 100, 668), 0.3), generator=g)
     r = torch.exp(torch.randn(512, 100, 668, generator=g) * 0.3 - 1.2)
     assert bits_per_spike(r.cuda(), s.cuda()) == pytest.approx(MO.bits_per_spike(r.numpy(), s.numpy()), rel=2e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_bits_per_spike_per_neuron_vs_reference_fixture():
+    from multi_modal_foundation_model_amd.metrics import bits_per_spike_per_neuron
+    z, meta = load_npz("eval_metrics.npz")
+    for c in meta["cases"]:
+        r, s = torch.from_numpy(z[f"c{c['id']}/rates"]).cuda(), torch.from_numpy(z[f"c{c['id']}/spikes"]).cuda()
+        got = bits_per_spike_per_neuron(r, s).cpu().numpy()
+        np.testing.assert_allclose(got, z[f"c{c['id']}/bps_per_neuron"], rtol=3e-5, atol=1e-6, equal_nan=True)
+    g = torch.Generator().manual_seed(3)                       # eval-sized: 512 trials x 100 bins x 668 neurons
+    s = torch.poisson(torch.full((512, 100, 668), 0.3), generator=g)
+    r = torch.exp(torch.randn(512, 100, 668, generator=g) * 0.3 - 1.2)
+    np.testing.assert_allclose(bits_per_spike_per_neuron(r.cuda(), s.cuda()).cpu().numpy(), MO.bits_per_spike_per_neuron(r.numpy(), s.numpy()),
+                               rtol=3e-5, atol=1e-6)
 
 
 @pytest.mark.gpu
