@@ -445,8 +445,9 @@ def test_gemm_bf16_linear_forward(ops, M, N, K):
     close_bf16(y, x.double() @ w.double().T + b.double(), f"bf16 linear {M}x{N}x{K}")
 
 
-def test_gemm_bf16_epilogues_and_layouts(ops):
-    M, N, K = 500, 512, 256
+@pytest.mark.parametrize("N", [512, 668, 12])          # 668 = 83 x 8 + 4: the 4-column-granular vector epilogue; 12: ragged, single tile
+def test_gemm_bf16_epilogues_and_layouts(ops, N):
+    M, K = 500, 256
     x, w, b, res = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2, scale=K ** -0.5)), rnd(N, seed=3), bf(rnd(M, N, seed=4))
     y, pre = torch.empty(M, N, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     ops.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b, pre_out=pre, act=1, residual=res, ldr=N)
@@ -539,6 +540,33 @@ def test_attention_bf16_fwd_bwd(ops, B, heads, L, dh, flags):
     oref.backward(d_o.float())
     for nm, sl in (("dq", slice(0, H)), ("dk", slice(H, 2 * H)), ("dv", slice(2 * H, 3 * H))):
         close_bf16(dqkv[:, sl], x.grad[:, sl], f"bf16 attn {nm}", tol=3e-2)
+
+
+@pytest.mark.parametrize("Lq,Lk,dh", [(72, 40, 32), (40, 72, 32), (200, 200, 64), (224, 100, 16)])
+def test_attention_bf16_cross_shapes(ops, Lq, Lk, dh):
+    """bf16 attention with Lq != Lk and no DIAG: Lk <= Lq runs the single-pass backward, Lk > Lq the two-phase kernels."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    B, heads = 2, 4
+    H = heads * dh
+    q, kv, d_o = bf(rnd(B * Lq, H, seed=1)), bf(rnd(B * Lk, 2 * H, seed=2)), bf(rnd(B * Lq, H, seed=3))
+    kp = torch.ones(B, Lk, dtype=torch.uint8)
+    kp[1, Lk - 5:] = 0
+    kp = kp.cuda()
+    o, lse = torch.empty(B * Lq, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, Lq, device="cuda")
+    dq, dkv = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
+    desc = ops.attn_desc(Lb.BF16, B, heads, Lq, Lk, dh, q.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * 2, H, 2 * H, 2 * H, o.data_ptr(), H, lse,
+                         kp, None, 0, dh ** -0.5, d_o=d_o.data_ptr(), lddo=H, dq=dq.data_ptr(), dk=dkv.data_ptr(),
+                         dv=dkv.data_ptr() + H * 2, lddq=H, lddk=2 * H, lddv=2 * H)
+    ops.attn_fwd(desc)
+    ops.attn_bwd(desc)
+    qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    Q = qr.view(B, Lq, heads, dh).transpose(1, 2)
+    K_, V_ = [t.view(B, Lk, heads, dh).transpose(1, 2) for t in kvr.split(H, dim=1)]
+    oref = ref_attention(Q, K_, V_, kp.bool()[:, None, :].expand(B, Lq, Lk), dh ** -0.5).transpose(1, 2).reshape(B * Lq, H)
+    close_bf16(o, oref, "bf16 xattn fwd", tol=2e-2)
+    oref.backward(d_o.float())
+    close_bf16(dq, qr.grad, "bf16 xattn dq", tol=3e-2)
+    close_bf16(dkv, kvr.grad, "bf16 xattn dkv", tol=3e-2)
 
 
 @pytest.mark.parametrize("L,dh", [(64, 32), (600, 64), (460, 64)])
