@@ -171,7 +171,6 @@ __device__ __forceinline__ void stg8(uint16_t* p, uint4 v, bool a16, bool hi, bo
 template <typename TO>
 __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int z, int vec_epi,
                                               int t, int wm, int wn, int kh, int l31) {
-    if ((vec_epi & 256) && acc[0][0][0] != 12345.678f) return;      // ablation hook: no epilogue (keeps the MFMAs live)
     // ---- epilogue.  Fast path (row-aligned shapes): the fp32 tile is staged through LDS half a tile at a time
     // (64 rows x 128 cols x 4 B = 32 KB, reusing the operand buffers) so that each thread owns 8 consecutive
     // columns of a row: bias/pre-activation/residual/output move as 16-B (bf16) or 2x16-B (fp32) accesses.
@@ -343,7 +342,7 @@ __global__ __launch_bounds__(NTHREADS, BK == 64 ? 3 : 2) void gemm_bf16_kernel(c
             r2s<ARC, BK>(As, ra, t);
             r2s<BRC, BK>(Bs, rb, t);
             __syncthreads();
-            if (!(vec_epi & 512)) {
+            {
                 if (k0 + BK < kend) {          // next K-slice of this tile
                     g2r<ARC, BK>(ra, A, d.lda, m0, k0 + BK, d.M, kend, alignA, t);
                     g2r<BRC, BK>(rb, B, d.ldb, n0, k0 + BK, d.N, kend, alignB, t);
@@ -427,11 +426,10 @@ int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     const int vec4 = (d.N % 4 == 0) && (d.ldc % 4 == 0) && (f32c ? al16(d.C) : al8(d.C)) && al8(d.pre_out) && al8(d.gradmul_pre) && al16(d.bias) &&
                      (!d.residual || (d.ldr % 4 == 0 && al8(d.residual))) && (!d.splits || d.splits == 1 || d.slab_stride % 4 == 0);
     const int vec = vec8 ? 1 : (vec4 ? 3 : 0);
-    static const int abl = [] { const char* e = getenv("MMFM_GEMM_ABLATE"); return e ? atoi(e) : 0; }();
     // MMFM_GEMM_NT: bit 0 = bf16 output C, bit 1 = saved pre-activation, bit 2 = fp32 output / split-K slabs stored non-temporally, bit 3 = residual / saved
     // pre-activation LOADED non-temporally
     static const int nt_env = [] { const char* e = getenv("MMFM_GEMM_NT"); return e ? atoi(e) : 3; }();
-    const int vecf = vec | (abl << 8) | ((nt_env & 1) ? 4096 : 0) | ((nt_env & 2) ? 8192 : 0) | ((nt_env & 4) ? 16384 : 0) | ((nt_env & 8) ? 32768 : 0);
+    const int vecf = vec | ((nt_env & 1) ? 4096 : 0) | ((nt_env & 2) ? 8192 : 0) | ((nt_env & 4) ? 16384 : 0) | ((nt_env & 8) ? 32768 : 0);
 #define LAUNCH2(ARC, BRC, BKV)                                                                                    \
     if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float, BKV>), grid, block, 0, st, d, aA, aB, vecf, total_items);  \
     else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t, BKV>), grid, block, 0, st, d, aA, aB, vecf, total_items);

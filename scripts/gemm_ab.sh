@@ -1,3 +1,6 @@
+# Build the committed library for the A side first:
+#   mkdir -p /tmp/prev scripts/ab && git archive HEAD multi_modal_foundation_model_amd/csrc include | tar -x -C /tmp/prev \
+#     && make -C /tmp/prev/multi_modal_foundation_model_amd/csrc -j8 && cp /tmp/prev/multi_modal_foundation_model_amd/libmmfm_hip.so scripts/ab/libmmfm_hip_prev.so
 # same-box A/B: committed build (scripts/ab/libmmfm_hip_prev.so) vs working tree, microbench then whole step
 echo "== prev"; MMFM_LIB=$PWD/scripts/ab/libmmfm_hip_prev.so timeout -k 10 120 python scripts/gemm_bench.py 1024 2>/dev/null | grep -E "qkv|proj|down|head"
 echo "== new";  timeout -k 10 120 python scripts/gemm_bench.py 1024 2>/dev/null | grep -E "qkv|proj|down|head"
