@@ -31,6 +31,23 @@ __global__ void dropout_apply_kernel(const T* __restrict__ src, T* __restrict__ 
         io<T>::st(dst + i, dr.apply(io<T>::ld(src + i), (uint64_t)i));
 }
 
+// bf16, n % 8 == 0, 16-B aligned: 8 elements per thread (the scalar kernel above moves 2 B per lane: 3.3 TB/s)
+__global__ __launch_bounds__(256) void dropout_apply8_kernel(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t n8, mmfm_dropout da) {
+    const Drop dr = drop_init(da);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 g = *reinterpret_cast<const uint4*>(src + 8 * i);
+        const uint32_t gw[4] = {g.x, g.y, g.z, g.w};
+        uint32_t ow[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v0 = dr.apply(__uint_as_float(gw[j] << 16), (uint64_t)(8 * i + 2 * j));
+            const float v1 = dr.apply(__uint_as_float(gw[j] & 0xffff0000u), (uint64_t)(8 * i + 2 * j + 1));
+            ow[j] = (uint32_t)f2bf(v0) | ((uint32_t)f2bf(v1) << 16);
+        }
+        *reinterpret_cast<uint4*>(dst + 8 * i) = make_uint4(ow[0], ow[1], ow[2], ow[3]);
+    }
+}
+
 __global__ void cast_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = f2bf(src[i]);
 }
@@ -52,6 +69,8 @@ extern "C" int mmfm_dropout_apply(int dtype, const void* src, void* dst, int64_t
     hipStream_t st = (hipStream_t)stream;
     if (dtype == MMFM_F32)
         hipLaunchKernelGGL(dropout_apply_kernel<float>, dim3(ew_blocks(n)), dim3(256), 0, st, (const float*)src, (float*)dst, n, drop);
+    else if (dtype == MMFM_BF16 && n % 8 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0)
+        hipLaunchKernelGGL(dropout_apply8_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, st, (const uint16_t*)src, (uint16_t*)dst, n / 8, drop);
     else if (dtype == MMFM_BF16)
         hipLaunchKernelGGL(dropout_apply_kernel<uint16_t>, dim3(ew_blocks(n)), dim3(256), 0, st, (const uint16_t*)src, (uint16_t*)dst, n, drop);
     else

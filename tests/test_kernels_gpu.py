@@ -430,6 +430,24 @@ def bf(t):
     return t.to(torch.bfloat16)
 
 
+@pytest.mark.parametrize("M,N", [(300, 256), (37, 12)])         # 16-B vector kernel / scalar kernel of mmfm_dropout_apply
+def test_gemm_bf16_dropout_matches_dropout_apply(ops, M, N):
+    """The backward of an MLP-output dropout re-applies the forward's mask with mmfm_dropout_apply: the mask must be the one
+    the bf16 GEMM epilogue drew (same site, same counter m*N + n), and kept values scale by 1/(1-p)."""
+    K, p = 64, 0.4
+    x, w = bf(rnd(M, K, seed=1)), bf(rnd(N, K, seed=2))
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 99)
+    y0, y1, y2 = (torch.empty(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    ops.gemm(x, w, y0, M, N, K, lda=K, ldb=K, ldc=N)
+    ops.gemm(x, w, y1, M, N, K, lda=K, ldb=K, ldc=N, drop=ops.dropout(state, 5, p))
+    ops.dropout_apply(y0, y2, M, N, ops.dropout(state, 5, p))
+    assert torch.equal((y1 != 0), (y2 != 0)) or ((y1 != 0) ^ (y2 != 0)).float().mean().item() < 1e-3     # exact zeros in y0 aside
+    nz = y2 != 0
+    close_bf16(y2[nz], (y0.float() / (1 - p))[nz], "bf16 dropout_apply scale", tol=1e-2)
+    assert abs(nz.float().mean().item() - (1 - p)) < (0.02 if M * N > 10000 else 0.15)
+
+
 def close_bf16(a, b, msg, tol=1.5e-2):
     a, b = a.float().cpu(), b.float().cpu()
     err = (a - b).abs().max().item()
