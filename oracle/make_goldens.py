@@ -627,7 +627,22 @@ def fx_eval_metrics():
         arrs[f"c{i}/bps_per_neuron"] = np.asarray([np.nan if np.isinf(b) else b for b in per], dtype=np.float64)
         cases.append(dict(id=i, bps=float(bits_per_spike(r32.copy(), s32)), nll=float(neg_log_likelihood(r32.copy(), s32))))
         print("   ", cases[-1])
-    arrs["meta"] = np.frombuffer(json.dumps(dict(cases=cases)).encode(), dtype=np.uint8)
+    # heldout_mask (utils/eval_utils.py:988-1045), every mode, on a small seeded array
+    from utils.eval_utils import heldout_mask
+    sp = torch.from_numpy(rng.poisson(0.8, (3, 6, 10)).astype(np.float32))
+    regions = np.array(["CA1", "PO", "CA1", "LP", "PO", "CA1", "LP", "PO", "CA1", "DG"])
+    hm_cases = [dict(mode="manual", heldout_idxs=[1, 4, 7]), dict(mode="most", n_active=3),
+                dict(mode="inter_region", heldout_idxs=[0, 2], target_regions=["CA1", "PO"]),
+                dict(mode="intra_region", heldout_idxs=[1], target_regions=["CA1"]),
+                dict(mode="intra_region", heldout_idxs=[], target_regions=["LP"]),
+                dict(mode="forward_pred", heldout_idxs=[4, 5]), dict(mode="modal_spike", heldout_idxs=[0, 3])]
+    arrs["hm/spikes"], arrs["hm/regions"] = sp.numpy(), np.frombuffer(json.dumps(regions.tolist()).encode(), dtype=np.uint8)
+    for j, kw in enumerate(hm_cases):
+        call = {k: (np.array(v) if k == "heldout_idxs" else v) for k, v in kw.items()}
+        out = heldout_mask(sp.clone(), neuron_regions=regions, **call)
+        arrs[f"hm/{j}/spikes"], arrs[f"hm/{j}/eval_mask"] = out["spikes"].numpy(), out["eval_mask"].numpy()
+        arrs[f"hm/{j}/heldout_idxs"] = np.asarray(out["heldout_idxs"], dtype=np.int64)
+    arrs["meta"] = np.frombuffer(json.dumps(dict(cases=cases, heldout=hm_cases)).encode(), dtype=np.uint8)
     save_npz("eval_metrics.npz", **arrs)
 
 

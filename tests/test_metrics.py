@@ -24,6 +24,24 @@ def test_bits_per_spike_per_neuron_oracle_vs_reference_fixture():
         np.testing.assert_allclose(MO.bits_per_spike_per_neuron(r, s), z[f"c{c['id']}/bps_per_neuron"], rtol=1e-12, equal_nan=True)
 
 
+def test_heldout_mask_bit_exact_vs_reference_fixture():
+    """utils/eval_utils.py:988-1045, every evaluation mode: zeroed spikes, eval mask and held-out indices, exactly."""
+    import json
+    from utils.eval_utils import heldout_mask
+    z, meta = load_npz("eval_metrics.npz")
+    sp = torch.from_numpy(z["hm/spikes"])
+    regions = np.array(json.loads(bytes(z["hm/regions"]).decode()))
+    for j, kw in enumerate(meta["heldout"]):
+        call = {k: (np.array(v, dtype=np.int64) if k == "heldout_idxs" else v) for k, v in kw.items()}
+        out = heldout_mask(sp.clone(), neuron_regions=regions, **call)
+        np.testing.assert_array_equal(out["spikes"].numpy(), z[f"hm/{j}/spikes"], err_msg=str(kw))
+        np.testing.assert_array_equal(out["eval_mask"].numpy(), z[f"hm/{j}/eval_mask"], err_msg=str(kw))
+        assert out["eval_mask"].dtype == torch.int64
+        np.testing.assert_array_equal(np.asarray(out["heldout_idxs"], dtype=np.int64), z[f"hm/{j}/heldout_idxs"], err_msg=str(kw))
+    with pytest.raises(NotImplementedError):
+        heldout_mask(sp, mode="per_neuron")
+
+
 def test_r2_oracle_vs_sklearn():
     from sklearn.metrics import r2_score
     rng = np.random.default_rng(0)
@@ -61,6 +79,10 @@ def test_gpu_bits_per_spike_per_neuron_vs_reference_fixture():
         r, s = torch.from_numpy(z[f"c{c['id']}/rates"]).cuda(), torch.from_numpy(z[f"c{c['id']}/spikes"]).cuda()
         got = bits_per_spike_per_neuron(r, s).cpu().numpy()
         np.testing.assert_allclose(got, z[f"c{c['id']}/bps_per_neuron"], rtol=3e-5, atol=1e-6, equal_nan=True)
+    from utils.eval_utils import bits_per_spike_per_neuron as bpsn_np, bits_per_spike as bps_np       # numpy in, like upstream
+    c = meta["cases"][1]
+    np.testing.assert_allclose(bpsn_np(z["c1/rates"], z["c1/spikes"]), z["c1/bps_per_neuron"], rtol=3e-5, atol=1e-6, equal_nan=True)
+    assert bps_np(z["c1/rates"], z["c1/spikes"]) == pytest.approx(c["bps"], rel=2e-5)
     g = torch.Generator().manual_seed(3)                       # eval-sized: 512 trials x 100 bins x 668 neurons
     s = torch.poisson(torch.full((512, 100, 668), 0.3), generator=g)
     r = torch.exp(torch.randn(512, 100, 668, generator=g) * 0.3 - 1.2)
