@@ -252,10 +252,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
                 acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Ks, (kt * 32 + l31) * KRS + ks * 32 + kh * 16), qf[ks], acc_s, 0, 0, 0);
             return acc_s;
         };
-        f32x16 st_next = score(0);
-        for (int kt = 0; kt < nkt; ++kt) {
-            const f32x16 st = st_next;
-            if (kt + 1 < nkt) st_next = score(kt + 1);
+        // one key tile: softmax algebra on its scores, then O^T += V^T P^T
+        auto tile = [&](int kt, const f32x16& st) {
             float alpha, pd[16];
             bool live;
             // valid keys of this tile in groups of 8; with no mask in play and whole groups the mask-free code runs on
@@ -268,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
             else
                 live = dp.on ? fwd_tile<false, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G)
                              : fwd_tile<false, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G);
-            if (!live) continue;
+            if (!live) return;
             const bf16x8v pf0 = pack8(pd), pf1 = pack8(pd + 8);
             const bool rescale = !__all(alpha == 1.f);
 #pragma unroll
@@ -279,6 +277,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
                 }
                 acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, VRS, kt * 32, i * 32, lane), pf0, acc[i], 0, 0, 0);
                 if (G > 2) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, VRS, kt * 32 + 16, i * 32, lane), pf1, acc[i], 0, 0, 0);
+            }
+        };
+        // two score tiles in flight, ping-pong (no accumulator copies: a rotating `st = st_next` costs 32 v_mov per tile in
+        // this VALU-bound loop): the scores of tile kt+1 are issued before the element-wise work of tile kt
+        f32x16 s0 = score(0), s1;
+        for (int kt = 0; kt < nkt; kt += 2) {
+            const bool has1 = kt + 1 < nkt;
+            if (has1) s1 = score(kt + 1);
+            tile(kt, s0);
+            if (has1) {
+                if (kt + 2 < nkt) s0 = score(kt + 2);
+                tile(kt + 1, s1);
             }
         }
         const float l_tot = l_run + __shfl_xor(l_run, 32);
