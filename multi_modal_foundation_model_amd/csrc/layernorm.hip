@@ -4,6 +4,7 @@
 // HBM-bound: algorithmic bytes fwd = 2*R*H*sizeof(T) (+8R stats), bwd = 4*R*H*sizeof(T).
 #include "common.h"
 #include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -15,7 +16,9 @@ __device__ __forceinline__ int64_t destitch_row(int64_t r, int L, int T, int64_t
     return (int64_t)(l / T) * (Btot * T) + b * T + (l % T);
 }
 
-// NV = 256-column chunks per lane (H <= 256*NV); UNR = rows a wave keeps in flight per iteration.  The kernels are
+// NV = 256-column chunks per lane (H <= 256*NV); UNR = rows a wave keeps in flight per iteration.  Measured at [204800, 256]
+// bf16 (scripts/ln_bench.py): forward 41 us (5.1 TB/s) at UNR = 1 or 2, 56 us at 4, 63 us at 8 (registers cost more
+// waves than the extra rows in flight buy); backward 135 / 113 / 103 us at UNR = 1 / 2 / 4.  The kernels are
 // latency-bound at one row per wave (16 waves/CU x 1.5 KB in flight = 3 TB/s by Little's law, measured 137 us for
 // the [204800, 256] bf16 backward = 3.07 TB/s): all loads of UNR consecutive rows are issued before the first use.
 template <typename T, int NV, int UNR>
@@ -191,8 +194,14 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize(const float* __restrict__
 
 // enough workgroups to fill every wave slot of the chip (256 CUs x 8 blocks of 4 waves): streaming kernels
 // hide HBM latency with waves in flight; the backward keeps fewer blocks (its per-block partials are reduced after)
-int ln_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(2048, (R + 15) / 16)); }
-int ln_bwd_blocks(int64_t R) { return (int)std::max<int64_t>(1, std::min<int64_t>(1024, (R + 15) / 16)); }
+int ln_blocks(int64_t R) {
+    static const int cap = [] { const char* e = getenv("MMFM_LN_FWD_BLOCKS"); return e ? atoi(e) : 2048; }();
+    return (int)std::max<int64_t>(1, std::min<int64_t>(cap, (R + 15) / 16));
+}
+int ln_bwd_blocks(int64_t R) {
+    static const int cap = [] { const char* e = getenv("MMFM_LN_BWD_BLOCKS"); return e ? atoi(e) : 1024; }();
+    return (int)std::max<int64_t>(1, std::min<int64_t>(cap, (R + 15) / 16));
+}
 
 }  // namespace
 
@@ -208,7 +217,8 @@ extern "C" int mmfm_layernorm_fwd(int dtype, const void* x, const float* gamma, 
     hipStream_t st = (hipStream_t)stream;
     if (dtype != MMFM_F32 && dtype != MMFM_BF16) return mmfm_set_error(-1, "mmfm_layernorm_fwd: bad dtype %d", dtype);
 #define LN_FWD(TT, NVV, UU) hipLaunchKernelGGL((ln_fwd_kernel<TT, NVV, UU>), grid, block, 0, st, (const TT*)x, gamma, beta, (TT*)y, mean, rstd, R, H, eps, dsL, dsT)
-#define LN_FWD_T(TT) if (H <= 256) LN_FWD(TT, 1, 4); else if (H <= 512) LN_FWD(TT, 2, 2); else LN_FWD(TT, 4, 1)
+    static const int fwd_unr = [] { const char* e = getenv("MMFM_LN_FWD_UNR"); return e ? atoi(e) : 2; }();
+#define LN_FWD_T(TT) if (H <= 256) { if (fwd_unr == 8) LN_FWD(TT, 1, 8); else if (fwd_unr == 2) LN_FWD(TT, 1, 2); else if (fwd_unr == 1) LN_FWD(TT, 1, 1); else LN_FWD(TT, 1, 4); } else if (H <= 512) LN_FWD(TT, 2, 2); else LN_FWD(TT, 4, 1)
     if (dtype == MMFM_F32) { LN_FWD_T(float); } else { LN_FWD_T(uint16_t); }
 #undef LN_FWD_T
 #undef LN_FWD
@@ -231,7 +241,8 @@ extern "C" int mmfm_layernorm_bwd(int dtype, const void* dy, const void* x, cons
     hipStream_t st = (hipStream_t)stream;
     if (dtype != MMFM_F32 && dtype != MMFM_BF16) return mmfm_set_error(-1, "mmfm_layernorm_bwd: bad dtype %d", dtype);
 #define LN_BWD(TT, NVV, UU) hipLaunchKernelGGL((ln_bwd_kernel<TT, NVV, UU>), dim3(nblk), dim3(256), lds, st, (const TT*)dy, (const TT*)x, mean, rstd, gamma, (const TT*)dres, (TT*)dx, (float*)workspace, R, H, dsL, dsT)
-#define LN_BWD_T(TT) if (H <= 256) LN_BWD(TT, 1, 4); else if (H <= 512) LN_BWD(TT, 2, 2); else LN_BWD(TT, 4, 1)
+    static const int bwd_unr = [] { const char* e = getenv("MMFM_LN_BWD_UNR"); return e ? atoi(e) : 4; }();
+#define LN_BWD_T(TT) if (H <= 256) { if (bwd_unr == 2) LN_BWD(TT, 1, 2); else if (bwd_unr == 1) LN_BWD(TT, 1, 1); else LN_BWD(TT, 1, 4); } else if (H <= 512) LN_BWD(TT, 2, 2); else LN_BWD(TT, 4, 1)
     if (dtype == MMFM_F32) { LN_BWD_T(float); } else { LN_BWD_T(uint16_t); }
 #undef LN_BWD_T
 #undef LN_BWD
