@@ -22,6 +22,53 @@ except Exception:          # pragma: no cover
 OBJECTIVES = ['encoding', 'decoding', 'token_masking']
 
 
+class LazyRegions:
+    """The [B, N] region array `np.asarray(batch['neuron_regions']).T` of trainer/base.py:57, built on first use.
+
+    Converting the collated list of N lists of B strings costs 34 ms per step at B = 1024 (as much host time as the whole
+    GPU step), and on this path nobody reads it after the masker's first call: the model accepts temporal masking only
+    (mm.py:66) and the masker touches the regions once, to expand 'all' (masker.py:72-76).  Behaves like the ndarray for
+    readers: `np.asarray(x)`, `np.unique(x)`, `x == region`, indexing, `.shape`."""
+    __slots__ = ("_raw", "_arr")
+
+    def __init__(self, raw):
+        self._raw, self._arr = raw, None
+
+    def materialize(self):
+        if self._arr is None:
+            self._arr = np.asarray(self._raw).T
+        return self._arr
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.materialize()
+        return a if dtype is None else a.astype(dtype)
+
+    def __eq__(self, other):
+        return self.materialize() == other
+
+    def __ne__(self, other):
+        return self.materialize() != other
+
+    __hash__ = None
+
+    def __getitem__(self, idx):
+        return self.materialize()[idx]
+
+    def __len__(self):
+        return len(self.materialize())
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    @property
+    def shape(self):
+        return self.materialize().shape
+
+    @property
+    def T(self):
+        return self.materialize().T
+
+
 class MultiModalTrainer():
     def __init__(self, model, train_dataloader, eval_dataloader, optimizer, **kwargs):
         self.model = model
@@ -56,7 +103,6 @@ class MultiModalTrainer():
         # modality-index scalars (a pageable H2D copy each = a stream drain per call) and the [B, N] region array
         self._mod_index_cache = {}
         self._const_mask_cache = {}
-        self._regions_cache = (None, None)
 
     # ------------------------------------------------------------------ batch -> mod_dict (trainer/base.py:51-103)
     def _forward_model_outputs(self, batch, masking_mode, training_mode):
@@ -89,10 +135,7 @@ class MultiModalTrainer():
                 # (upstream clones twice; nothing on this path writes into either tensor - the masker works on its own
                 # clone and the engine copies inputs/targets into its static buffers - so the 2 x 274 MB copies are dropped)
                 d['inputs'], d['targets'] = spikes, spikes
-                regions = batch['neuron_regions']
-                if self._regions_cache[0] is not regions:          # same session object -> same [B, N] array
-                    self._regions_cache = (regions, np.asarray(regions).T)
-                d['inputs_regions'] = self._regions_cache[1]
+                d['inputs_regions'] = LazyRegions(batch['neuron_regions'])
             elif mod == 'behavior':
                 d['inputs'], d['targets'] = behav, behav
             else:
