@@ -159,3 +159,21 @@ def test_context_mask_helper():
     m = create_context_mask(0, -1, 5)
     assert torch.equal(m, torch.tril(torch.ones(5, 5, dtype=torch.int64)))
     assert torch.equal(create_context_mask(-1, -1, 4), torch.ones(4, 4, dtype=torch.int64))
+
+
+def test_lazy_regions_behaves_like_the_region_array():
+    """trainer/base.py:57 builds np.asarray(batch['neuron_regions']).T every step; the mirror defers it (34 ms of host time
+    at B = 1024) behind an object that reads like that array."""
+    from trainer.base import LazyRegions
+    raw = [["CA1", "CA1", "PO"], ["LP", "LP", "LP"], ["PO", "CA1", "PO"], ["nan", "nan", "nan"]]      # N = 4 lists of B = 3 strings
+    want = np.asarray(raw).T
+    lz = LazyRegions(raw)
+    assert lz._arr is None                                   # nothing converted yet
+    np.testing.assert_array_equal(np.asarray(lz), want)
+    assert lz.shape == (3, 4) and len(lz) == 3
+    np.testing.assert_array_equal(np.unique(lz), np.unique(want))
+    np.testing.assert_array_equal(lz == "PO", want == "PO")
+    np.testing.assert_array_equal(lz != "PO", want != "PO")
+    np.testing.assert_array_equal(lz[1], want[1])
+    np.testing.assert_array_equal(lz.T, want.T)
+    assert [list(r) for r in lz] == [list(r) for r in want]
