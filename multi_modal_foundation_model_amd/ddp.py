@@ -92,13 +92,12 @@ class DataParallelModel(torch.nn.Module):
         self._pg, self._bucket_bytes, self._ddp = process_group, bucket_bytes, None
 
     def forward(self, *a, **kw):
-        out = self.module(*a, **kw)
-        eng = self.module._engine
+        eng = self.module.engine()           # builds / re-adopts the engine from the module's current parameters
         if self._ddp is None or self._ddp.engine is not eng:
-            # first step: replicas were built from the same seed, but make it exact anyway; the broadcast
-            # happens after this forward, so step 0's loss is per-rank local and its update is synchronised
+            # like torch DDP's constructor: rank 0's parameters are broadcast BEFORE the first forward, so every replica's
+            # first loss and gradient are taken at the same parameters even if the replicas were initialised differently
             self._ddp = EngineDDP(eng, self._pg, self._bucket_bytes, broadcast=True)
-        return out
+        return self.module(*a, **kw)
 
     def __getattr__(self, name):
         try:

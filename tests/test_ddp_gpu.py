@@ -1,0 +1,94 @@
+"""The N > 1 path with the REAL engine: two ranks (processes) on the one GPU of the test box, gloo for the collective (RCCL
+needs one GPU per rank; the driver's 8-GPU run exercises it).  Checks what tests/test_ddp_cpu.py checks on a stand-in, end
+to end: hipGraph-replayed backward segments with the bucketed all-reduce issued between them, parameters broadcast from
+rank 0, and after three optimiser steps both replicas equal the single-process emulation that averages the per-rank
+gradients of the per-rank normalised losses."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+STEPS, WORLD, B, T, N_AP, N_BEH = 3, 2, 4, 8, 12, 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _paths():
+    for p in (ROOT, os.path.join(ROOT, "multi_modal_foundation_model_amd", "src"), os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+
+
+def _batch(rank, step):
+    from oracle import mm_oracle as O
+    md = O.make_mod_dict(O.synth_batch(B, T, N_AP, N_BEH, seed=100 * rank + step), ("encoding", "decoding", "encoding")[step])
+    for d in md.values():
+        for k, v in list(d.items()):
+            if isinstance(v, torch.Tensor):
+                d[k] = v.cuda()
+        d["targets_modality"], d["targets_timestamp"] = d["inputs_modality"], d["inputs_timestamp"]
+    return md
+
+
+def _worker(rank, port, out_dir):
+    _paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from helpers import build_model, make_optimizer, tiny_config
+    from multi_modal_foundation_model_amd.ddp import DataParallelModel
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    model = build_model(tiny_config(n_enc=2, n_dec=2), N_AP, N_BEH, seed=7 + rank).cuda().train()     # replicas differ until the broadcast
+    ddp = DataParallelModel(model, bucket_bytes=16 << 10)            # small buckets: several collectives per backward
+    opt, sch = make_optimizer(ddp, 10)
+    losses = []
+    for s in range(STEPS):
+        out = ddp(_batch(rank, s))
+        out.loss.backward()
+        opt.step(); sch.step(); opt.zero_grad()
+        losses.append(out.loss.item())
+    assert len(ddp._ddp.buckets.buckets) >= 3
+    torch.save(dict(state={k: v.detach().cpu() for k, v in model.state_dict().items()}, losses=losses), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_the_gradient_averaging_emulation(tmp_path):
+    _paths()
+    mp.spawn(_worker, args=(_free_port(), str(tmp_path)), nprocs=WORLD, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=True)
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=True)
+    for k in r0["state"]:
+        assert torch.equal(r0["state"][k], r1["state"][k]), f"replicas diverged: {k}"
+    # emulation in this process: rank 0's initial parameters, per-rank gradients averaged, one optimiser step per step
+    from helpers import build_model, make_optimizer, tiny_config
+    model = build_model(tiny_config(n_enc=2, n_dec=2), N_AP, N_BEH, seed=7).cuda().train()
+    opt, sch = make_optimizer(model, 10)
+    for s in range(STEPS):
+        grads, losses = None, []
+        for rank in range(WORLD):
+            opt.zero_grad()
+            out = model(_batch(rank, s))
+            out.loss.backward()
+            losses.append(out.loss.item())
+            g = model._engine.G.clone()
+            grads = g if grads is None else grads + g
+        model._engine.G.copy_(grads / WORLD)
+        opt.step(); sch.step()
+        assert losses[0] == pytest.approx(r0["losses"][s], rel=1e-5) and losses[1] == pytest.approx(r1["losses"][s], rel=1e-5), s
+    opt.zero_grad()
+    for k, v in model.state_dict().items():
+        np.testing.assert_allclose(v.detach().cpu().numpy(), r0["state"][k].numpy(), rtol=2e-5, atol=2e-7, err_msg=k)
