@@ -143,10 +143,18 @@ def main():
         torch.set_num_threads(max(1, min(len(os.sched_getaffinity(0)), 16)))
     except AttributeError:
         pass
+    # rehearsal switch for a one-GPU box: every rank on cuda:0 and gloo instead of RCCL (which needs one GPU per rank), so the
+    # N > 1 control flow of this script (barriers, max-over-ranks timing, rank-0 JSON) can be exercised before an 8-GPU run
+    rehearse = os.environ.get("MMFM_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from helpers import build_model, load_config
     from torch.optim.lr_scheduler import OneCycleLR
