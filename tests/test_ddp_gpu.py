@@ -92,3 +92,39 @@ def test_two_ranks_match_the_gradient_averaging_emulation(tmp_path):
     opt.zero_grad()
     for k, v in model.state_dict().items():
         np.testing.assert_allclose(v.detach().cpu().numpy(), r0["state"][k].numpy(), rtol=2e-5, atol=2e-7, err_msg=k)
+
+
+def _rccl_worker(rank, port, out_dir):
+    _paths()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    from helpers import build_model, make_optimizer, tiny_config
+    from multi_modal_foundation_model_amd.ddp import DataParallelModel
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)         # RCCL, as bench.py / Accelerator initialise it
+    finals = []
+    for wrap in (True, False):
+        model = build_model(tiny_config(n_enc=2, n_dec=2), N_AP, N_BEH, seed=7).cuda().train()
+        m = DataParallelModel(model, bucket_bytes=16 << 10) if wrap else model
+        opt, sch = make_optimizer(m, 10)
+        for s in range(STEPS):
+            out = m(_batch(0, s))
+            out.loss.backward()
+            opt.step(); sch.step(); opt.zero_grad()
+        if wrap:
+            assert m._ddp.avg_op is not None and len(m._ddp.buckets.buckets) >= 3
+        finals.append({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    torch.save(finals, os.path.join(out_dir, "rccl.pt"))
+    dist.destroy_process_group()
+
+
+def test_rccl_collective_path_single_rank(tmp_path):
+    """RCCL needs one GPU per rank, so with one GPU only world_size 1 can run it: the AVG all-reduce is then an identity,
+    but the calls are the ones the 8-GPU run makes (nccl backend bound to the device, async bucket all-reduces issued between
+    the hipGraph-replayed backward segments, stream-side wait before the optimiser).  Result must equal the unwrapped run."""
+    _paths()
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    with_ddp, without = torch.load(os.path.join(tmp_path, "rccl.pt"), weights_only=True)
+    for k in without:
+        assert torch.equal(with_ddp[k], without[k]), k
