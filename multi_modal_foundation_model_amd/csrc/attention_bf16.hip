@@ -870,6 +870,375 @@ bool bwd1_ok(int Lq, int Lk, int dh) {
     return !off && LkP <= 32 * BW1_CW && LkP <= LqP && (size_t)LkP * RS <= (size_t)2 * BW1_CW * BW1_TILE && bwd1_lds(Lq, Lk, dh) <= 160 * 1024;
 }
 
+// ============================================================================ tiled bf16 kernels (long sequences)
+// Heads whose K/V (forward) or Q/dO/K/V (backward) images do not fit the 160 KB of LDS (BASELINE config 5: L = 600,
+// dh = 64).  grid = (B*heads, ceil(tiles/4)): a workgroup OWNS four 32-row tiles, one per wave, whose operands live in
+// registers (straight from global memory), and STREAMS the other side through LDS in 128-row chunks, keeping the running
+// softmax state / the gradient accumulators in registers across chunks.  Same element-wise code, masks, dropout hash and
+// mask-free fast path as the untiled kernels; no atomics, fixed summation order.
+constexpr int TCH16 = 128;       // streamed rows per chunk
+
+template <int DH>
+__global__ __launch_bounds__(256, 2) void attn_fwd_bf16_tiled_kernel(const mmfm_attn_desc d) {
+    constexpr int NW = 4, KS = DH / 16, DT = (DH + 31) / 32;
+    constexpr int KRS = DH * 2 + 16, VRS = DT * 64, SLD = DT * 32 + 1, NT = NW * 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, kh = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int Lq = d.Lq, Lk = d.Lk, LkP = (Lk + 31) & ~31, Lmx = max(Lq, Lk);
+    char* Ks = smem;                                   // [TCH16][KRS]
+    char* Vs = Ks + TCH16 * KRS;                       // [TCH16][VRS]
+    float* Sc = reinterpret_cast<float*>(Vs + TCH16 * VRS);
+    int* wflag = reinterpret_cast<int*>(Sc + NW * 32 * SLD);
+    uint8_t* kpad = reinterpret_cast<uint8_t*>(wflag + NW);
+    uint8_t* modl = kpad + LkP;
+    const uint16_t* qg = reinterpret_cast<const uint16_t*>(d.q) + (size_t)b * Lq * d.ldq + h * DH;
+    const uint16_t* kg = reinterpret_cast<const uint16_t*>(d.k) + (size_t)b * Lk * d.ldk + h * DH;
+    const uint16_t* vg = reinterpret_cast<const uint16_t*>(d.v) + (size_t)b * Lk * d.ldv + h * DH;
+    uint16_t* og = reinterpret_cast<uint16_t*>(d.o) + (size_t)b * Lq * d.ldo + h * DH;
+
+    int allk = 1;
+    for (int i = t; i < LkP; i += NT) {
+        const uint8_t v = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
+        kpad[i] = v;
+        if (i < Lk) allk &= (v != 0);
+    }
+    if (d.flags & MMFM_ATTN_SEP)
+        for (int i = t; i < Lmx; i += NT) modl[i] = d.mod_id[i];
+    const int wave_vote = __all(allk) ? 1 : 0;
+    if (lane == 0) wflag[wave] = wave_vote;
+    __syncthreads();
+    int vote = 1;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) vote &= wflag[w];
+    const bool nomask = vote && !(d.flags & (MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP));
+
+    const MaskCtx mk{kpad, modl, d.flags};
+    const Drop16 dp = drop16_init(d.drop_p);
+    const Drop dout = drop_init(d.drop_o);
+    float* sc = Sc + wave * 32 * SLD;
+    const int nqt = (Lq + 31) / 32, LkH = (Lk + 1) >> 1;
+    const float c2 = d.scale * LOG2E;
+    const int qt = blockIdx.y * NW + wave;
+    const bool active = qt < nqt;                      // inactive waves still take part in the chunk barriers
+    const int q0 = qt * 32, q = q0 + l31;
+    const uint32_t pair_base = ((uint32_t)blockIdx.x * (uint32_t)Lq + (uint32_t)q) * (uint32_t)LkH;
+    bf16x8v qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (active && q < Lq) v = *reinterpret_cast<const uint4*>(qg + (size_t)q * d.ldq + ks * 16 + 8 * kh);
+        qf[ks] = __builtin_bit_cast(bf16x8v, v);
+    }
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 acc[DT];
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    for (int c0 = 0; c0 < LkP; c0 += TCH16) {
+        const int rows = min(TCH16, LkP - c0);
+        __syncthreads();                               // readers of the previous chunk are done
+        load_head16<DH>(Ks, KRS, KRS / 16, kg + (size_t)c0 * d.ldk, d.ldk, max(0, min(rows, Lk - c0)), rows, t, NT);
+        load_head16<DH>(Vs, VRS, VRS / 16, vg + (size_t)c0 * d.ldv, d.ldv, max(0, min(rows, Lk - c0)), rows, t, NT);
+        __syncthreads();
+        if (!active) continue;
+        auto score = [&](int kl) {
+            f32x16 acc_s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_s[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                acc_s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Ks, (kl * 32 + l31) * KRS + ks * 32 + kh * 16), qf[ks], acc_s, 0, 0, 0);
+            return acc_s;
+        };
+        auto tile = [&](int kl, const f32x16& st) {
+            const int kt = c0 / 32 + kl;               // global key tile: key indices and the dropout counters
+            float alpha, pd[16];
+            bool live;
+            const int nk = min(32, Lk - kt * 32), G = (nk + 7) >> 3;
+            if (nomask && (nk & 7) == 0)
+                live = dp.on ? fwd_tile<true, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G)
+                             : fwd_tile<true, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G);
+            else
+                live = dp.on ? fwd_tile<false, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G)
+                             : fwd_tile<false, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G);
+            if (!live) return;
+            const bf16x8v pf0 = pack8(pd), pf1 = pack8(pd + 8);
+            const bool rescale = !__all(alpha == 1.f);
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                if (rescale) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][r] *= alpha;
+                }
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, VRS, kl * 32, i * 32, lane), pf0, acc[i], 0, 0, 0);
+                if (G > 2) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, VRS, kl * 32 + 16, i * 32, lane), pf1, acc[i], 0, 0, 0);
+            }
+        };
+        const int nkl = rows / 32;
+        f32x16 s0 = score(0), s1;
+        for (int kl = 0; kl < nkl; kl += 2) {
+            const bool has1 = kl + 1 < nkl;
+            if (has1) s1 = score(kl + 1);
+            tile(kl, s0);
+            if (has1) {
+                if (kl + 2 < nkl) s0 = score(kl + 2);
+                tile(kl + 1, s1);
+            }
+        }
+    }
+    if (!active) return;                               // no barrier below
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.f / l_tot;
+    if (kh == 0 && q < Lq) d.lse[(size_t)blockIdx.x * Lq + q] = m_run * LN2 + __logf(l_tot);
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < DT; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[l31 * SLD + i * 32 + mrow(r, kh)] = acc[i][r] * inv;
+    wave_lds_fence();
+    constexpr int C4 = DH / 4;
+    for (int idx = lane; idx < 32 * C4; idx += 64) {
+        const int row = idx / C4, c = idx % C4;
+        if (q0 + row < Lq) {
+            const float* p = sc + row * SLD + 4 * c;
+            const uint64_t base = ((uint64_t)b * Lq + (uint64_t)(q0 + row)) * (uint64_t)(d.heads * DH) + (uint64_t)(h * DH + 4 * c);
+            float4 v;
+            v.x = dout.apply(p[0], base + 0); v.y = dout.apply(p[1], base + 1);
+            v.z = dout.apply(p[2], base + 2); v.w = dout.apply(p[3], base + 3);
+            io<uint16_t>::st4(og + (size_t)(q0 + row) * d.ldo + 4 * c, v);
+        }
+    }
+}
+
+// PHASE 0: the workgroup owns 4 key tiles (dK, dV; K/V operands in registers) and streams Q / dO chunks;
+// PHASE 1: owns 4 query tiles (dQ; Q/dO operands and delta in registers) and streams K / V chunks.
+template <int DH, int PHASE>
+__global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_attn_desc d) {
+    constexpr int NW = 4, KS = DH / 16, DT = (DH + 31) / 32;
+    constexpr int RS = DH * 2 + 16, NT = NW * 64, C8 = DH / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int t = threadIdx.x, lane = t & 63, kh = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int Lq = d.Lq, Lk = d.Lk, LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31, Lmx = max(Lq, Lk);
+    char* As = smem;                                  // phase 0: Q chunk     phase 1: K chunk     [TCH16][RS]
+    char* Bs = As + TCH16 * RS;                       // phase 0: dO chunk    phase 1: V chunk
+    float* lse2 = reinterpret_cast<float*>(Bs + TCH16 * RS);   // phase 0: lse * log2(e) of the chunk  [TCH16]
+    float* dlt = lse2 + TCH16;                                 // phase 0: delta of the chunk          [TCH16]
+    char* Sc = reinterpret_cast<char*>(dlt + TCH16);           // [NW][32 rows x RS] output transpose tiles
+    int* wflag = reinterpret_cast<int*>(Sc + NW * 32 * RS);
+    uint8_t* kpad = reinterpret_cast<uint8_t*>(wflag + NW);
+    uint8_t* modl = kpad + LkP;
+    const uint16_t* qg = reinterpret_cast<const uint16_t*>(d.q) + (size_t)b * Lq * d.ldq + h * DH;
+    const uint16_t* kg = reinterpret_cast<const uint16_t*>(d.k) + (size_t)b * Lk * d.ldk + h * DH;
+    const uint16_t* vg = reinterpret_cast<const uint16_t*>(d.v) + (size_t)b * Lk * d.ldv + h * DH;
+    const uint16_t* og = reinterpret_cast<const uint16_t*>(d.o) + (size_t)b * Lq * d.ldo + h * DH;
+    const uint16_t* dog = reinterpret_cast<const uint16_t*>(d.d_o) + (size_t)b * Lq * d.lddo + h * DH;
+    const Drop16 dp = drop16_init(d.drop_p);
+    const Drop dout = drop_init(d.drop_o);
+
+    int allk = 1;
+    for (int i = t; i < LkP; i += NT) {
+        const uint8_t v = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
+        kpad[i] = v;
+        if (i < Lk) allk &= (v != 0);
+    }
+    if (d.flags & MMFM_ATTN_SEP)
+        for (int i = t; i < Lmx; i += NT) modl[i] = d.mod_id[i];
+    const int wave_vote = __all(allk) ? 1 : 0;
+    if (lane == 0) wflag[wave] = wave_vote;
+    __syncthreads();
+    int vote = 1;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) vote &= wflag[w];
+    const bool nomask = vote && !(d.flags & (MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP));
+
+    const MaskCtx mk{kpad, modl, d.flags};
+    const int LkH = (Lk + 1) >> 1;
+    const uint32_t pbase = (uint32_t)blockIdx.x * (uint32_t)Lq;
+    const float c2 = d.scale * LOG2E;
+    char* sct = Sc + wave * 32 * RS;
+
+    if constexpr (PHASE == 0) {
+        const int kt = blockIdx.y * NW + wave;
+        const bool active = kt < LkP / 32;
+        f32x16 dKt[DT], dVt[DT];
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { dKt[i][r] = 0.f; dVt[i][r] = 0.f; }
+        const int key = kt * 32 + l31;
+        bf16x8v kfr[KS], vfr[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
+            if (active && key < Lk) {
+                kv = *reinterpret_cast<const uint4*>(kg + (size_t)key * d.ldk + ks * 16 + 8 * kh);
+                vv = *reinterpret_cast<const uint4*>(vg + (size_t)key * d.ldv + ks * 16 + 8 * kh);
+            }
+            kfr[ks] = __builtin_bit_cast(bf16x8v, kv);
+            vfr[ks] = __builtin_bit_cast(bf16x8v, vv);
+        }
+        for (int c0 = 0; c0 < LqP; c0 += TCH16) {
+            const int rows = min(TCH16, LqP - c0);
+            __syncthreads();
+            load_head16<DH>(As, RS, RS / 16, qg + (size_t)c0 * d.ldq, d.ldq, max(0, min(rows, Lq - c0)), rows, t, NT);
+            for (int idx = t; idx < rows * C8; idx += NT) {              // dO = dropout'(d_o) as bf16;  delta = rowsum(d_o * o)
+                const int row = idx / C8, c = idx % C8, qrow = c0 + row;
+                uint4 g = make_uint4(0u, 0u, 0u, 0u), o = g;
+                if (qrow < Lq) {
+                    g = *reinterpret_cast<const uint4*>(dog + (size_t)qrow * d.lddo + 8 * c);
+                    o = *reinterpret_cast<const uint4*>(og + (size_t)qrow * d.ldo + 8 * c);
+                }
+                const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, ow[4] = {o.x, o.y, o.z, o.w};
+                const uint64_t base = ((uint64_t)b * Lq + (uint64_t)qrow) * (uint64_t)(d.heads * DH) + (uint64_t)(h * DH + 8 * c);
+                float part = 0.f, gd[8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float g0 = __uint_as_float(gw[j] << 16), g1 = __uint_as_float(gw[j] & 0xffff0000u);
+                    const float o0 = __uint_as_float(ow[j] << 16), o1 = __uint_as_float(ow[j] & 0xffff0000u);
+                    part += g0 * o0 + g1 * o1;
+                    gd[2 * j] = dout.apply(g0, base + 2 * j);
+                    gd[2 * j + 1] = dout.apply(g1, base + 2 * j + 1);
+                }
+#pragma unroll
+                for (int off = 1; off < C8; off <<= 1) part += __shfl_xor(part, off);
+                if (c == 0) dlt[row] = part;
+                *reinterpret_cast<uint4*>(Bs + row * RS + c * 16) = __builtin_bit_cast(uint4, pack8(gd));
+            }
+            constexpr int PADC = RS / 16 - C8;
+            for (int idx = t; idx < rows * PADC; idx += NT)
+                *reinterpret_cast<uint4*>(Bs + (idx / PADC) * RS + (C8 + idx % PADC) * 16) = make_uint4(0u, 0u, 0u, 0u);
+            for (int i = t; i < rows; i += NT) lse2[i] = (c0 + i < Lq) ? d.lse[(size_t)blockIdx.x * Lq + c0 + i] * LOG2E : 0.f;
+            __syncthreads();
+            if (!active) continue;
+            const float* lse2g = lse2 - c0;            // indexed by the GLOBAL query
+            const float* dltg = dlt - c0;
+            for (int ql = 0; ql < rows / 32; ++ql) {
+                const int qt = c0 / 32 + ql;
+                f32x16 s, dpv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dpv[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int off = (ql * 32 + l31) * RS + ks * 32 + kh * 16;
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(As, off), kfr[ks], s, 0, 0, 0);
+                    dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Bs, off), vfr[ks], dpv, 0, 0, 0);
+                }
+                const int nq = min(32, Lq - qt * 32), GRP = (nq + 7) >> 3;
+                const bool full = nomask && (nq & 7) == 0;
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    if (2 * s2 >= GRP) continue;
+                    float pd[8], ds[8];
+                    if (full) {
+                        if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                        else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                    } else {
+                        if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                        else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                    }
+                    const bf16x8v pf = pack8(pd), sf = pack8(ds);
+#pragma unroll
+                    for (int i = 0; i < DT; ++i) {
+                        dVt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Bs, RS, ql * 32 + 16 * s2, i * 32, lane), pf, dVt[i], 0, 0, 0);
+                        dKt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(As, RS, ql * 32 + 16 * s2, i * 32, lane), sf, dKt[i], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (!active) return;
+        store_tile_T<DH, DT>(sct, RS, dKt, reinterpret_cast<uint16_t*>(d.dk) + (size_t)b * Lk * d.lddk + h * DH, d.lddk, kt * 32, Lk, lane);
+        store_tile_T<DH, DT>(sct, RS, dVt, reinterpret_cast<uint16_t*>(d.dv) + (size_t)b * Lk * d.lddv + h * DH, d.lddv, kt * 32, Lk, lane);
+    } else {
+        const int qt = blockIdx.y * NW + wave;
+        const bool active = qt < LqP / 32;
+        f32x16 dQt[DT];
+#pragma unroll
+        for (int i = 0; i < DT; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dQt[i][r] = 0.f;
+        const int q = qt * 32 + l31;
+        bf16x8v qfr[KS], dofr[KS];
+        float dpart = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            uint4 qv = make_uint4(0u, 0u, 0u, 0u), g = qv, o = qv;
+            if (active && q < Lq) {
+                qv = *reinterpret_cast<const uint4*>(qg + (size_t)q * d.ldq + ks * 16 + 8 * kh);
+                g = *reinterpret_cast<const uint4*>(dog + (size_t)q * d.lddo + ks * 16 + 8 * kh);
+                o = *reinterpret_cast<const uint4*>(og + (size_t)q * d.ldo + ks * 16 + 8 * kh);
+            }
+            qfr[ks] = __builtin_bit_cast(bf16x8v, qv);
+            const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, ow[4] = {o.x, o.y, o.z, o.w};
+            const uint64_t base = ((uint64_t)b * Lq + (uint64_t)q) * (uint64_t)(d.heads * DH) + (uint64_t)(h * DH + ks * 16 + 8 * kh);
+            float gd[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float g0 = __uint_as_float(gw[j] << 16), g1 = __uint_as_float(gw[j] & 0xffff0000u);
+                const float o0 = __uint_as_float(ow[j] << 16), o1 = __uint_as_float(ow[j] & 0xffff0000u);
+                dpart += g0 * o0 + g1 * o1;
+                gd[2 * j] = dout.apply(g0, base + 2 * j);
+                gd[2 * j + 1] = dout.apply(g1, base + 2 * j + 1);
+            }
+            dofr[ks] = pack8(gd);
+        }
+        const float dq_ = dpart + __shfl_xor(dpart, 32);
+        const float lq = (active && q < Lq) ? d.lse[(size_t)blockIdx.x * Lq + q] * LOG2E : 0.f;
+        const uint32_t pair_base = (pbase + (uint32_t)q) * (uint32_t)LkH;
+        for (int c0 = 0; c0 < LkP; c0 += TCH16) {
+            const int rows = min(TCH16, LkP - c0);
+            __syncthreads();
+            load_head16<DH>(As, RS, RS / 16, kg + (size_t)c0 * d.ldk, d.ldk, max(0, min(rows, Lk - c0)), rows, t, NT);
+            load_head16<DH>(Bs, RS, RS / 16, vg + (size_t)c0 * d.ldv, d.ldv, max(0, min(rows, Lk - c0)), rows, t, NT);
+            __syncthreads();
+            if (!active) continue;
+            for (int kl = 0; kl < rows / 32; ++kl) {
+                const int kt = c0 / 32 + kl;
+                f32x16 s, dpv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[r] = 0.f; dpv[r] = 0.f; }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int off = (kl * 32 + l31) * RS + ks * 32 + kh * 16;
+                    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(As, off), qfr[ks], s, 0, 0, 0);          // S^T[key][q]
+                    dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Bs, off), dofr[ks], dpv, 0, 0, 0);     // dP^T[key][q]
+                }
+                float ds[16];
+                const bool full = nomask && (kt * 32 + 32 <= Lk) && (qt * 32 + 32 <= Lq);
+                if (full) {
+                    if (dp.on) bwdB_tile<true, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
+                    else bwdB_tile<true, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
+                } else {
+                    if (dp.on) bwdB_tile<false, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
+                    else bwdB_tile<false, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
+                }
+                const bf16x8v sf[2] = {pack8(ds), pack8(ds + 8)};
+#pragma unroll
+                for (int i = 0; i < DT; ++i)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+                        dQt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(As, RS, kl * 32 + 16 * s2, i * 32, lane), sf[s2], dQt[i], 0, 0, 0);
+            }
+        }
+        if (!active) return;
+        store_tile_T<DH, DT>(sct, RS, dQt, reinterpret_cast<uint16_t*>(d.dq) + (size_t)b * Lq * d.lddq + h * DH, d.lddq, qt * 32, Lq, lane);
+    }
+}
+
+size_t fwd_tiled16_lds(int Lq, int Lk, int dh) {
+    const int DT = (dh + 31) / 32, LkP = (Lk + 31) & ~31;
+    return (size_t)TCH16 * (dh * 2 + 16) + (size_t)TCH16 * DT * 64 + (size_t)4 * 32 * (DT * 32 + 1) * 4 + 16 + LkP + std::max(Lq, Lk) + 64;
+}
+size_t bwd_tiled16_lds(int Lq, int Lk, int dh) {
+    const int LkP = (Lk + 31) & ~31, RS = dh * 2 + 16;
+    return (size_t)2 * TCH16 * RS + (size_t)2 * TCH16 * 4 + (size_t)4 * 32 * RS + 16 + LkP + std::max(Lq, Lk) + 64;
+}
+
 // waves per workgroup (MMFM_ATTN_FWD_WAVES / MMFM_ATTN_BWD_WAVES = 4 or 8).  Smaller workgroups let more of them
 // co-reside on a CU, which is what hides each workgroup's dispatch + load prologue.
 int env_waves(const char* name, int dflt) {
@@ -911,12 +1280,43 @@ int mmfm_attn_bf16_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st
     const bool al = d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.ldo % 8 == 0 && (uintptr_t)d.q % 16 == 0 &&
                     (uintptr_t)d.k % 16 == 0 && (uintptr_t)d.v % 16 == 0 && (uintptr_t)d.o % 16 == 0;
     if (!al) return -1000;
-    {   // shape decision shared by forward and backward (see use_tiled in attention.hip): all three kernels must fit
-        static const bool force_tiled = [] { const char* e = getenv("MMFM_ATTN_FORCE_TILED"); return e && atoi(e) != 0; }();
-        if (force_tiled) return -1000;
+    {   // shape decision shared by forward and backward (see use_tiled in attention.hip): the untiled kernels are used only
+        // if all three fit; otherwise the tiled bf16 kernels take forward AND backward (one dropout hash layout per pair).
+        // MMFM_ATTN_FORCE_TILED: 1 = tiled bf16 kernels for every shape, 2 = hand the call to the fp32-compute tiled kernels.
+        static const int force_env = [] { const char* e = getenv("MMFM_ATTN_FORCE_TILED"); return e ? atoi(e) : 0; }();
+        if (force_env == 2) return -1000;
         const int nwf = fwd_waves(), nwb = bwd_waves();
-        if (fwd_lds(d.Lq, d.Lk, d.dh, nwf) > 160 * 1024 || bwd_lds(d.Lq, d.Lk, d.dh, nwb, 0) > 160 * 1024 ||
-            bwd_lds(d.Lq, d.Lk, d.dh, nwb, 1) > 160 * 1024) return -1000;
+        const bool fits = fwd_lds(d.Lq, d.Lk, d.dh, nwf) <= 160 * 1024 && bwd_lds(d.Lq, d.Lk, d.dh, nwb, 0) <= 160 * 1024 &&
+                          bwd_lds(d.Lq, d.Lk, d.dh, nwb, 1) <= 160 * 1024;
+        if (!fits || force_env == 1) {
+            const int gq = ((d.Lq + 31) / 32 + 3) / 4, gk = ((d.Lk + 31) / 32 + 3) / 4;
+#define TILED16(KERN, GY, LDSB)                                                                                   \
+            {                                                                                                     \
+                auto kern = KERN;                                                                                 \
+                if (int rc = opt_in_lds(reinterpret_cast<const void*>(kern), LDSB)) return rc;                    \
+                hipLaunchKernelGGL(kern, dim3(d.B * d.heads, GY), dim3(256), LDSB, st, d);                        \
+            }
+            if (backward) {
+                const bool alb = d.lddo % 8 == 0 && d.lddq % 8 == 0 && d.lddk % 8 == 0 && d.lddv % 8 == 0 && (uintptr_t)d.d_o % 16 == 0 &&
+                                 (uintptr_t)d.dq % 16 == 0 && (uintptr_t)d.dk % 16 == 0 && (uintptr_t)d.dv % 16 == 0;
+                if (!alb) return mmfm_set_error(-1, "mmfm_attn_bwd(bf16, tiled): gradient tensors must be 16-byte aligned with leading dims % 8 == 0");
+                const size_t lds = bwd_tiled16_lds(d.Lq, d.Lk, d.dh);
+                if (lds > 160 * 1024) return -1000;
+                if (d.dh == 16) { TILED16((attn_bwd_bf16_tiled_kernel<16, 0>), gk, lds) TILED16((attn_bwd_bf16_tiled_kernel<16, 1>), gq, lds) }
+                else if (d.dh == 32) { TILED16((attn_bwd_bf16_tiled_kernel<32, 0>), gk, lds) TILED16((attn_bwd_bf16_tiled_kernel<32, 1>), gq, lds) }
+                else { TILED16((attn_bwd_bf16_tiled_kernel<64, 0>), gk, lds) TILED16((attn_bwd_bf16_tiled_kernel<64, 1>), gq, lds) }
+                MMFM_LAUNCH_CHECK("mmfm_attn_bwd(bf16, tiled)");
+            } else {
+                const size_t lds = fwd_tiled16_lds(d.Lq, d.Lk, d.dh);
+                if (lds > 160 * 1024 || bwd_tiled16_lds(d.Lq, d.Lk, d.dh) > 160 * 1024) return -1000;
+                if (d.dh == 16) TILED16((attn_fwd_bf16_tiled_kernel<16>), gq, lds)
+                else if (d.dh == 32) TILED16((attn_fwd_bf16_tiled_kernel<32>), gq, lds)
+                else TILED16((attn_fwd_bf16_tiled_kernel<64>), gq, lds)
+                MMFM_LAUNCH_CHECK("mmfm_attn_fwd(bf16, tiled)");
+            }
+#undef TILED16
+            return 0;
+        }
     }
     if (backward) {
         const bool alb = d.lddo % 8 == 0 && d.lddq % 8 == 0 && d.lddk % 8 == 0 && d.lddv % 8 == 0 && (uintptr_t)d.d_o % 16 == 0 &&
