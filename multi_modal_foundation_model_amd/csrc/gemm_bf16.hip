@@ -430,9 +430,11 @@ int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     // pre-activation LOADED non-temporally
     static const int nt_env = [] { const char* e = getenv("MMFM_GEMM_NT"); return e ? atoi(e) : 3; }();
     const int vecf = vec | ((nt_env & 1) ? 4096 : 0) | ((nt_env & 2) ? 8192 : 0) | ((nt_env & 4) ? 16384 : 0) | ((nt_env & 8) ? 32768 : 0);
+    // occupancy probe: unused dynamic LDS bytes per workgroup (60000 -> one workgroup per CU less, 100000 -> one per CU)
+    static const int pad_lds = [] { const char* e = getenv("MMFM_GEMM_PAD_LDS"); return e ? atoi(e) : 0; }();
 #define LAUNCH2(ARC, BRC, BKV)                                                                                    \
-    if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float, BKV>), grid, block, 0, st, d, aA, aB, vecf, total_items);  \
-    else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t, BKV>), grid, block, 0, st, d, aA, aB, vecf, total_items);
+    if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float, BKV>), grid, block, pad_lds, st, d, aA, aB, vecf, total_items);  \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t, BKV>), grid, block, pad_lds, st, d, aA, aB, vecf, total_items);
 #define LAUNCH(ARC, BRC) if (BKsel == 128) { LAUNCH2(ARC, BRC, 128) } else { LAUNCH2(ARC, BRC, 64) }
     if (d.a_kcontig && d.b_kcontig) { LAUNCH(false, false) }
     else if (d.a_kcontig && !d.b_kcontig) { LAUNCH(false, true) }
