@@ -447,9 +447,10 @@ def fx_config5_scalars():
     save_json("config5_scalars.json", res)
 
 
-def fx_trainer_io():
-    """The reference trainer on 3 synthetic batches (wandb / torcheval stubbed)."""
-    import transformers  # noqa: F401  (import before stubbing, SURVEY.md §8c)
+def _stub_wandb_torcheval():
+    """wandb and torcheval are not installed here: utils/metric_utils.py and trainer/base.py import them at module load.  The
+    stand-ins are shared by every fixture that imports those modules (first registration wins in sys.modules); R2Score is a
+    working 1 - SS_res / SS_tot so that the trainer fixture can run its evaluation."""
     wb = types.ModuleType("wandb")
     wb.log = lambda *a, **k: None
     wb.Image = lambda x: x
@@ -475,6 +476,12 @@ def fx_trainer_io():
     te.metrics = tem
     sys.modules.setdefault("torcheval", te)
     sys.modules.setdefault("torcheval.metrics", tem)
+
+
+def fx_trainer_io():
+    """The reference trainer on 3 synthetic batches (wandb / torcheval stubbed)."""
+    import transformers  # noqa: F401  (import before stubbing, SURVEY.md §8c)
+    _stub_wandb_torcheval()
     import matplotlib
     matplotlib.use("Agg")
     from trainer.make import make_multimodal_trainer
@@ -598,17 +605,12 @@ def fx_multisession_curve():
 
 def fx_eval_metrics():
     """The reference's own bits_per_spike / neg_log_likelihood (utils/eval_utils.py:1051-1119) on seeded rate / spike arrays.
-    eval_utils imports torcheval (absent) through utils.metric_utils at module load: a placeholder module satisfies the import;
-    nothing of it runs in these two functions."""
+    eval_utils imports torcheval (absent) through utils.metric_utils at module load: the shared stand-in satisfies the import;
+    nothing of it runs in these functions."""
     import datasets
     if not hasattr(datasets, "list_datasets"):
         datasets.list_datasets = lambda *a, **k: []
-    te, tem = types.ModuleType("torcheval"), types.ModuleType("torcheval.metrics")
-    tem.R2Score = type("R2Score", (), {"__init__": lambda self, *a, **k: None})
-    te.metrics = tem
-    sys.modules.setdefault("torcheval", te)
-    sys.modules.setdefault("torcheval.metrics", tem)
-    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    _stub_wandb_torcheval()
     import matplotlib
     matplotlib.use("Agg")
     from utils.eval_utils import bits_per_spike, neg_log_likelihood
