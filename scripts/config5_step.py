@@ -6,7 +6,7 @@ for p in (ROOT, os.path.join(ROOT, "multi_modal_foundation_model_amd", "src"), o
     sys.path.insert(0, p)
 import torch
 from helpers import build_model_mods, make_optimizer, model_config
-from oracle import mm_oracle as O
+import numpy as np
 sys.path.insert(0, ROOT)
 import importlib.util
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
@@ -18,12 +18,20 @@ model.loss_mod["lfp"] = "mse"
 model.compute_dtype = "bf16"
 model = model.cuda().train()
 opt, sch = make_optimizer(model, 1000)
-batch = O.synth_batch_mods(B, 200, mods, seed=0)
-_dev = O.make_mod_dict_mods(batch, mods, "ap")
-for x in _dev.values():
-    for k, v in list(x.items()):
-        if isinstance(v, torch.Tensor): x[k] = v.cuda()
-    x["targets_modality"], x["targets_timestamp"] = x["inputs_modality"], x["inputs_timestamp"]
+# synthetic batch (SURVEY.md 8d recipe: Poisson(0.3) spikes, N(0,1) for the other modalities), 'ap' fully masked
+g = torch.Generator().manual_seed(0)
+T = 200
+attn = torch.ones(B, T, dtype=torch.int64).cuda()
+ts = torch.arange(T, dtype=torch.int64)[None].repeat(B, 1).cuda()
+_dev = {}
+for i, (name, n) in enumerate(mods):
+    x = (torch.poisson(torch.full((B, T, n), 0.3), generator=g) if name == "ap" else torch.randn(B, T, n, generator=g)).cuda()
+    idx = torch.tensor(i).cuda()
+    _dev[name] = dict(inputs_modality=idx, targets_modality=idx, inputs_attn_mask=attn, inputs_timestamp=ts, targets_timestamp=ts,
+                      masking_mode=None, inputs=x, targets=x,
+                      eval_mask=torch.full((1, 1, 1), 1 if name == "ap" else 0, dtype=torch.int64, device="cuda").expand(B, T, n))
+    if name == "ap":
+        _dev[name]["inputs_regions"] = np.full((B, n), "XX")
 def md():                                    # inputs resident in HBM, a fresh (shallow) mod_dict per step like the trainer builds
     return {m: dict(x) for m, x in _dev.items()}
 def step():
