@@ -193,7 +193,14 @@ class Engine:
         K.rng_seed(self.rng, seed)
         self.params: Dict[str, torch.nn.Parameter] = {}
         self.plans: Dict[Tuple, dict] = {}
-        self.b: Dict[str, torch.Tensor] = {}
+        # Buffers are owned per batch shape (B, T): a plan (and its captured hipGraphs) holds raw device pointers, so a
+        # buffer must never be re-allocated while a plan that names it is alive.  `self.b` is the pool of the shape in
+        # use; pools (with their plans) are evicted least-recently-used beyond MMFM_MAX_SHAPES.
+        self._pools: Dict[Tuple[int, int], Dict[str, torch.Tensor]] = {}
+        self._pool_lru: List[Tuple[int, int]] = []
+        self.max_shapes = max(1, int(os.environ.get("MMFM_MAX_SHAPES", "4")))
+        self._shared: Dict[str, torch.Tensor] = {}
+        self.b: Dict[str, torch.Tensor] = self._shared
         self._shape = None
         self._token = 0
         self._fwd_token = -1
@@ -203,9 +210,9 @@ class Engine:
         # hipGraph replay of the step plan: the plan neither allocates nor synchronises, so after one eager
         # (warm-up) run per batch shape it is captured once and replayed.  MMFM_GRAPH=0 disables.
         self.use_graphs = os.environ.get("MMFM_GRAPH", "1") != "0"
-        self.b["loss"] = torch.zeros(1, device=self.device)
-        self.b["inv_n"] = torch.zeros(1, device=self.device)
-        self.b["gout"] = torch.ones(1, device=self.device)
+        self._shared["loss"] = torch.zeros(1, device=self.device)
+        self._shared["inv_n"] = torch.zeros(1, device=self.device)
+        self._shared["gout"] = torch.ones(1, device=self.device)
 
     # ------------------------------------------------------------------ parameters
     def adopt(self, named_params: Dict[str, torch.nn.Parameter]):
@@ -249,12 +256,35 @@ class Engine:
         return self.layout.view(self.G, name)
 
     # ------------------------------------------------------------------ buffers
+    def _select_pool(self, B, T):
+        """Make the buffer pool of batch shape (B, T) current (creating it, and evicting the least recently used
+        shape - pool, plans and graphs together - beyond `max_shapes`)."""
+        key = (B, T)
+        pool = self._pools.get(key)
+        if pool is None:
+            while len(self._pools) >= self.max_shapes:
+                old = self._pool_lru.pop(0)
+                torch.cuda.synchronize(self.device)          # nothing may still be replaying the evicted graphs
+                for pk in [k for k in self.plans if (k[0], k[1]) == old]:
+                    del self.plans[pk]
+                del self._pools[old]
+            pool = dict(self._shared)
+            self._pools[key] = pool
+        if key in self._pool_lru:
+            self._pool_lru.remove(key)
+        self._pool_lru.append(key)
+        self.b = pool
+        return pool
+
     def _buf(self, name, shape, dtype=None, zero=False):
         dtype = self.adt if dtype is None else dtype
         t = self.b.get(name)
-        if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+        if t is None:
             t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
             self.b[name] = t
+        elif tuple(t.shape) != tuple(shape) or t.dtype != dtype:
+            raise RuntimeError(f"engine buffer {name}: {tuple(t.shape)}/{t.dtype} re-requested as {tuple(shape)}/{dtype} "
+                               "inside one batch-shape pool (plans hold raw pointers; buffers are never re-allocated)")
         return t
 
     def _site(self, key):
@@ -280,6 +310,7 @@ class Engine:
 
     def _plan(self, B, T, training):
         key = (B, T, bool(training))
+        self._select_pool(B, T)
         if key in self.plans:
             return self.plans[key]
         c = self.cfg
@@ -521,7 +552,7 @@ class Engine:
                      act=L.ACT_SOFTSIGN_GRAD, act_scale=c.embed_scale, gradmul_pre=self.b[f"{side}/z/{m}"])
                 dlin(cur, dz, self.b[f"in/{m}"], p + ".token_embed", BT, n2, n)
         close_segment("embed")
-        plan = dict(fwd=fwd, bwd=bwd, B=B, T=T, training=bool(training), M=M, R=R, BT=BT, runs=dict(fwd=0, bwd=0), graphs={})
+        plan = dict(fwd=fwd, bwd=bwd, B=B, T=T, training=bool(training), M=M, R=R, BT=BT, runs=dict(fwd=0, bwd=0), graphs={}, b=self.b)
         self.plans[key] = plan
         return plan
 
@@ -590,6 +621,9 @@ class Engine:
         if first is not None and first.grad is not None:
             accumulate_into = self.G.clone()               # caller did not zero_grad(): keep torch's += semantics
         plan = self._last
+        if (plan["B"], plan["T"]) not in self._pools or self._pools[(plan["B"], plan["T"])] is not plan["b"]:
+            raise RuntimeError("backward(): the batch shape of this loss was evicted (MMFM_MAX_SHAPES) before its backward ran")
+        self.b = plan["b"]
         if self.grad_ready_hooks and accumulate_into is None:
             for name, seg in plan["bwd"]:          # DDP: one graph per segment, collectives issued in between
                 self._run(plan, "bwd", lambda seg=seg: K.run_plan(seg), tag="bwd/" + name)

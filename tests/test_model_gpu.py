@@ -341,3 +341,52 @@ def test_bf16_loss_curve_stays_near_fp32():
     model.cuda()
     losses = run_curve(model, 12, 16, 100, 668, 2, 1000, g["objective"])
     np.testing.assert_allclose(losses, g["loss"][:12], rtol=2e-2)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_alternating_batch_shapes_keep_their_plans(dtype):
+    """A ragged last batch (the reference DataLoader has no drop_last) changes (B, T) and comes back: every cached plan
+    and captured hipGraph must keep pointing at live buffers.  B = 6 -> 3 -> 6 -> 3 in train and eval, against an
+    engine that only ever saw one shape."""
+    mc = tiny_config(n_enc=2, n_dec=2)
+
+    def fresh():
+        m = build_model(mc, 12, 2, seed=7)
+        m.compute_dtype = dtype
+        return m.cuda()
+
+    def step(model, B, seed, train):
+        model.train(train)
+        md = to_dev(O.make_mod_dict(O.synth_batch(B, 8, 12, 2, seed=seed), "encoding"))
+        if not train:
+            with torch.no_grad():
+                return model(md).loss.item(), None
+        model.zero_grad(set_to_none=True)
+        out = model(md)
+        out.loss.backward()
+        return out.loss.item(), model._engine.G.clone()
+
+    seq = [(6, 0, True), (6, 1, True), (6, 2, True), (3, 3, True), (6, 4, True), (3, 5, False), (6, 6, False), (6, 7, True),
+           (3, 8, True), (3, 9, True), (3, 10, True), (6, 11, True)]
+    mixed = fresh()
+    got = [step(mixed, *a) for a in seq]
+    for (B, seed, train), (loss, G) in zip(seq, got):
+        ref = fresh()
+        for _ in range(3):                       # run the single-shape engine past its graph capture as well
+            l_ref, G_ref = step(ref, B, seed, train)
+        assert loss == l_ref, (B, seed, train)
+        if G is not None:
+            torch.testing.assert_close(G, G_ref, rtol=0, atol=0)
+    assert len(mixed._engine._pools) == 2
+
+
+def test_shape_pool_eviction_drops_plans(monkeypatch):
+    monkeypatch.setenv("MMFM_MAX_SHAPES", "2")
+    model = build_model(tiny_config(), 12, 2, seed=7).cuda().eval()
+    losses = {}
+    with torch.no_grad():
+        for B in (2, 3, 4, 2, 3, 4):
+            l = model(to_dev(O.make_mod_dict(O.synth_batch(B, 8, 12, 2, seed=B), "encoding"))).loss.item()
+            assert losses.setdefault(B, l) == l
+    eng = model._engine
+    assert len(eng._pools) == 2 and all((k[0], k[1]) in eng._pools for k in eng.plans)
