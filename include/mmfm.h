@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MMFM_VERSION 100
+#define MMFM_VERSION 200
 #define MMFM_F32 0
 #define MMFM_BF16 1
 
@@ -234,6 +234,93 @@ int mmfm_bits_per_spike(const float* rates, const float* spikes, int64_t R, int 
 int64_t mmfm_bits_per_spike_neurons_workspace(int64_t R, int N);
 int mmfm_bits_per_spike_neurons(const float* rates, const float* spikes, int64_t R, int N, float* out,
                                 void* workspace, int64_t workspace_bytes, mmfm_stream stream);
+
+
+/* ---------------------------------------------------------------------------------- row-owner fused kernels (bf16, width 256)
+ * Throughput-mode kernels in which a wavefront owns 32 token rows and keeps them in registers through a chain of ops while
+ * the weights stream through LDS (csrc/rowchain.h).  They replace, for hidden_size 256 / inter_size 512 in bf16 mode, the
+ * LayerNorm + nn.Linear pairs, the attention out_proj + residual, the whole MLP block and their autograd
+ * (encoder_embeddings.py:106-116, decoder_embeddings.py:133-147, mm_utils.py:42-52,107-114,145-152, mm.py:290-292).
+ *
+ * mmfm_prep_weights: per training step (weights change) the LayerNorm affine is folded into the linear it feeds,
+ *   Wp[n][k] = bf16(W[n][k] * gamma[k]),  WpT = Wp^T,  bp[n] = bias[n] + sum_k W[n][k] * beta[k]
+ * so that  linear(layernorm(x)) = Wp . x_hat + bp  with  x_hat = (x - mean) * rstd.  gamma / beta / bias / Wp / WpT / bp may be
+ * NULL (plain bf16 copies / transposes of a weight).  `entries` is a DEVICE array; entry e covers blocks
+ * [tile0, tile0 + ceil(N/32)); total_tiles = sum of ceil(N/32). */
+typedef struct {
+    const float* W;          /* [N][K] fp32 master weight */
+    const float* gamma;      /* [K] or NULL */
+    const float* beta;       /* [K] or NULL */
+    const float* bias;       /* [N] or NULL */
+    void* Wp;                /* bf16 [N][K] or NULL */
+    void* WpT;               /* bf16 [K][N] or NULL */
+    float* bp;               /* fp32 [N] or NULL */
+    int N, K;
+    int tile0;
+    int pad_;
+} mmfm_prep_entry;
+int mmfm_prep_weights(const mmfm_prep_entry* entries, int n_entries, int total_tiles, mmfm_stream stream);
+
+/* y[R][N] = epi( pro(x)[R][K] . w[N][K]^T ), bf16 storage, fp32 accumulate; K in {256, 512, 768}, N % 32 == 0.
+ *   ln != 0 (K = 256): pro(x) = x_hat = (x - mean(x)) * rstd(x) per row (statistics in fp32); x_hat (bf16 [R][256]) and rstd
+ *                      (fp32 [R]) are written when non-NULL (the backward's saved tensors); w / bias are the PREPARED Wp / bp.
+ *   epilogue: + bias[n], + residual[m*ldr + n], store.
+ *   ln_bwd != 0 (N = 256): v = x . w^T is d(x_hat) of a LayerNorm whose output fed the forward linear (w = WpT of it) and
+ *                      y = residual + bwd_rstd * (v - mean(v) - bwd_xhat * mean(v * bwd_xhat))   (residual = running gradient or NULL). */
+typedef struct {
+    int64_t R;
+    int K, N;
+    const void* x; int ldx;
+    const void* w; int ldw;
+    const float* bias;
+    int ln; float eps;
+    void* xhat; float* rstd;
+    const void* residual; int ldr;
+    void* y; int ldy;
+    int stream_out;          /* 1: non-temporal stores of y */
+    int rotate;              /* 1: workgroups start at different weight tiles (spreads the concurrent L2 reads) */
+    int ln_bwd;
+    const void* bwd_xhat; const float* bwd_rstd;
+} mmfm_rowgemm_desc;
+int mmfm_rowgemm(const mmfm_rowgemm_desc* d, mmfm_stream stream);
+
+/* The MLP block in one launch (mm_utils.py:42-52 behind ln2, encoder_embeddings.py:114, decoder_embeddings.py:145):
+ *   fwd:  y = x + dropout( down( gelu_erf( up( layernorm(x) ) ) ) )        the 512-wide intermediate never leaves the CU
+ *         w_up / b_up are the prepared (gamma / beta folded) [512][256] / [512]; w_down bf16 [256][512]; x_hat / rstd are
+ *         written for the backward.
+ *   bwd:  recomputes u = up(x_hat) and g = gelu(u) from the saved x_hat instead of loading them, and produces
+ *         t1 = dropout'(dy)                      [R][256]   (operand of dW_down = t1^T g, db_down = colsum t1)
+ *         g                                      [R][512]
+ *         du = (t1 . W_down) * gelu'(u)          [R][512]   (operand of G_up = du^T x_hat, db_up = colsum du)
+ *         dx = dy + LayerNorm'(du . Wp_up)       [R][256]   (LayerNorm backward in registers; needs w_up_t = Wp_up^T, w_down_t = W_down^T)
+ *   Weight / LayerNorm-parameter gradients then follow from mmfm_gemm (dW slabs) + mmfm_ln_linear_grad. */
+typedef struct {
+    int64_t R;
+    const void* x; int ldx;           /* fwd: residual stream in (bf16 [R][256]) */
+    float eps;
+    const void* w_up; const float* b_up;
+    const void* w_down; const float* b_down;
+    mmfm_dropout drop;
+    void* y; int ldy;
+    void* xhat; float* rstd;          /* fwd: out;  bwd: in */
+    /* backward only */
+    const void* dy; int lddy;
+    const void* w_down_t;             /* bf16 [512][256] */
+    const void* w_up_t;               /* bf16 [256][512] (prepared) */
+    void* t1; void* g; void* du;
+    void* dx; int lddx;
+    int rotate;                       /* 1: workgroups start at different intermediate tiles (spreads the concurrent L2 reads) */
+} mmfm_mlp_desc;
+int mmfm_mlp_fwd(const mmfm_mlp_desc* d, mmfm_stream stream);
+int mmfm_mlp_bwd(const mmfm_mlp_desc* d, mmfm_stream stream);
+
+/* Gradients of a LayerNorm-fed linear from the reduced weight-gradient GEMM against x_hat:
+ *   Gdb = [ G[N][K] | db[N] ],  G = dY^T x_hat,  db = colsum dY   (one mmfm_gemm + mmfm_reduce_slabs)
+ *   dW[n][k] = gamma[k] * G[n][k] + db[n] * beta[k];   dbias = db;
+ *   dgamma[k] (+)= sum_n W[n][k] * G[n][k];   dbeta[k] (+)= sum_n W[n][k] * db[n]      (accumulate_ln selects +=)
+ * No per-row reduction is needed for the LayerNorm parameters.  Deterministic. */
+int mmfm_ln_linear_grad(const float* Gdb, const float* W, const float* gamma, const float* beta, int N, int K,
+                        float* dW, float* dbias, float* dgamma, float* dbeta, int accumulate_ln, mmfm_stream stream);
 
 #ifdef __cplusplus
 }

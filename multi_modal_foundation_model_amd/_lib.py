@@ -52,6 +52,26 @@ class AttnDesc(C.Structure):
                 ("dv", C.c_void_p), ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int)]
 
 
+class PrepEntry(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("bias", C.c_void_p), ("Wp", C.c_void_p),
+                ("WpT", C.c_void_p), ("bp", C.c_void_p), ("N", C.c_int), ("K", C.c_int), ("tile0", C.c_int), ("pad_", C.c_int)]
+
+
+class RowGemmDesc(C.Structure):
+    _fields_ = [("R", C.c_int64), ("K", C.c_int), ("N", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int), ("w", C.c_void_p),
+                ("ldw", C.c_int), ("bias", C.c_void_p), ("ln", C.c_int), ("eps", C.c_float), ("xhat", C.c_void_p),
+                ("rstd", C.c_void_p), ("residual", C.c_void_p), ("ldr", C.c_int), ("y", C.c_void_p), ("ldy", C.c_int),
+                ("stream_out", C.c_int), ("rotate", C.c_int), ("ln_bwd", C.c_int), ("bwd_xhat", C.c_void_p), ("bwd_rstd", C.c_void_p)]
+
+
+class MlpDesc(C.Structure):
+    _fields_ = [("R", C.c_int64), ("x", C.c_void_p), ("ldx", C.c_int), ("eps", C.c_float), ("w_up", C.c_void_p),
+                ("b_up", C.c_void_p), ("w_down", C.c_void_p), ("b_down", C.c_void_p), ("drop", Dropout), ("y", C.c_void_p),
+                ("ldy", C.c_int), ("xhat", C.c_void_p), ("rstd", C.c_void_p), ("dy", C.c_void_p), ("lddy", C.c_int),
+                ("w_down_t", C.c_void_p), ("w_up_t", C.c_void_p), ("t1", C.c_void_p), ("g", C.c_void_p), ("du", C.c_void_p),
+                ("dx", C.c_void_p), ("lddx", C.c_int), ("rotate", C.c_int)]
+
+
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _PROTOS = {
     "mmfm_version": (C.c_int, []),
@@ -80,6 +100,11 @@ _PROTOS = {
     "mmfm_dropout_apply": (C.c_int, [_i, _vp, _vp, _i64, _i, Dropout, _vp]),
     "mmfm_cast_f32_to_bf16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "mmfm_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "mmfm_prep_weights": (C.c_int, [_vp, _i, _i, _vp]),
+    "mmfm_rowgemm": (C.c_int, [C.POINTER(RowGemmDesc), _vp]),
+    "mmfm_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), _vp]),
+    "mmfm_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), _vp]),
+    "mmfm_ln_linear_grad": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "mmfm_r2_series": (C.c_int, [_vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _i, _i, _i, _vp, _vp]),
     "mmfm_bits_per_spike_workspace": (C.c_int64, [_i64, _i]),
     "mmfm_bits_per_spike": (C.c_int, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),

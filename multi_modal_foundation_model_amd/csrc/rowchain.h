@@ -1,0 +1,383 @@
+// Row-owner building blocks (bf16 throughput mode, model width 256) shared by rowgemm.hip and mlp_fused.hip.
+//
+// Every transformer op on the path except attention is row-local, and the rows are many (R = B*L = 204,800 at the bench
+// batch) while the weights are tiny (<= 0.4 MB per matrix).  So a wavefront OWNS 32 token rows: it keeps them in registers
+// as MFMA operands / accumulators through a whole chain of ops (LayerNorm -> GEMM -> activation -> GEMM -> residual ...),
+// and the weights stream past it through LDS in 16 KB chunks shared by the workgroup's waves.  Activations cross HBM once
+// per chain instead of once per op, and a row's statistics (LayerNorm forward and backward) never leave its wave.
+//
+// Orientation: every product is computed TRANSPOSED, D[n][m] = sum_k W[n][k] * X[m][k], with the weight rows as the MFMA
+// A operand and the token rows as the B operand.  A 32x32 accumulator tile then has the token on the lane (m = lane & 31)
+// and, in its 16 registers, n = 8*(r>>2) + 4*(lane>>5) + (r&3): four CONSECUTIVE output features per register group, so
+//   * a row's full output (all n) lives in lanes m and m+32 -> row statistics are in-lane sums plus one lane exchange;
+//   * outputs leave as 16-B row-major pieces (v_permlane32_swap pairs the two half-waves' 8-B groups);
+//   * the tile, converted to bf16, IS the B operand of the next product that sums over n (cdna_hip_programming.md S3,
+//     "An accumulator tile as the next MFMA's operand"): the chain needs no LDS round trip and no lane movement.  Its k
+//     order inside a 16-deep step is permuted (element j of lane half h = k 8*(j>>2) + 4*h + (j&3)); the weight chunks
+//     that multiply such operands are staged with the same permutation (PERM images below).
+//
+// Weight ring: two 16 KB LDS slots per workgroup.  Chunk c+2 is in flight from L2 in staging registers while chunk c+1
+// is written to the free slot and chunk c is multiplied; ONE __syncthreads() per chunk (16 MFMAs per wave).  All loads
+// are ordinary loads, so hipcc's own s_waitcnt bookkeeping orders everything - and to let it COUNT (vmcnt(N), not
+// vmcnt(0): the vector-memory counter retires in order, so a conservative wait for a weight chunk would also wait for
+// the output stores issued after it) the chunk loops are straight-line code: activations move through raw buffer
+// loads / stores whose bounds check replaces every `if (row < R)` (out-of-range loads return 0, stores are dropped, a
+// NULL optional tensor is a zero-sized buffer), chunk indices are clamped instead of guarded, and biases live in LDS.
+#pragma once
+#include "common.h"
+
+namespace rowchain {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 opnd;      // one MFMA A/B operand: 8 bf16 (4 VGPRs)
+constexpr int CHUNK = 16384;                                    // bytes per weight chunk / LDS slot
+constexpr int LDS_BYTES = 2 * CHUNK;
+
+// Where a chunk comes from.  kind 0: [32 rows][256 k] read by operands in natural k order;  kind 1: the same block for
+// operands that were accumulator tiles (PERM);  kind 2: [256 rows][32 k] PERM (all eight 32-row tiles x one 32-deep k slice).
+struct WChunk {
+    const uint16_t* base;      // element (row 0, k 0) of the block; rows are K-contiguous, 16-B aligned
+    int ld;                    // row stride in elements (multiple of 8)
+    int kind;                  // all 32 (kind 0, 1) / 256 (kind 2) rows of the block exist
+};
+
+__device__ __forceinline__ opnd as_opnd(uint4 v) { return __builtin_bit_cast(opnd, v); }
+__device__ __forceinline__ uint4 as_u4(opnd v) { return __builtin_bit_cast(uint4, v); }
+
+// ---- bounds-checked activation tensors (raw buffer descriptors; byte offsets < 2^31, checked on the host)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+struct GBuf { __amdgpu_buffer_rsrc_t rs; };
+__device__ __forceinline__ GBuf gbuf(const void* p, int64_t bytes) {
+    GBuf b;
+    b.rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, p ? (int)bytes : 0, 0x00020000);
+    return b;
+}
+__device__ __forceinline__ uint4 ld16(const GBuf& b, uint32_t off) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b.rs, (int)off, 0, 0));
+}
+template <bool NTS>
+__device__ __forceinline__ void st16(const GBuf& b, uint32_t off, uint4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b.rs, (int)off, 0, NTS ? 2 : 0);
+}
+__device__ __forceinline__ float ld4f(const GBuf& b, uint32_t off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b.rs, (int)off, 0, 0));
+}
+__device__ __forceinline__ void st4f(const GBuf& b, uint32_t off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), b.rs, (int)off, 0, 0);
+}
+
+// NT threads move one chunk (1024 16-B pieces) global -> registers -> LDS slot
+template <int NT>
+__device__ __forceinline__ void stage_load(uint4 (&r)[1024 / NT], const WChunk& c, int t) {
+#pragma unroll
+    for (int q = 0; q < 1024 / NT; ++q) {
+        const int p = t + NT * q;
+        const int row = c.kind == 2 ? (p >> 2) : (p >> 5);
+        const int col = c.kind == 2 ? (p & 3) : (p & 31);
+        r[q] = *reinterpret_cast<const uint4*>(c.base + (size_t)row * c.ld + 8 * col);
+    }
+}
+template <int NT>
+__device__ __forceinline__ void stage_write(const uint4 (&r)[1024 / NT], int kind, char* slot, int t) {
+#pragma unroll
+    for (int q = 0; q < 1024 / NT; ++q) {
+        const int p = t + NT * q;
+        if (kind == 0) {                     // 512-B rows, 16-B chunk index XOR (row & 15): conflict-free ds_read_b128
+            const int row = p >> 5, col = p & 31;
+            *reinterpret_cast<uint4*>(slot + row * 512 + ((col ^ (row & 15)) << 4)) = r[q];
+        } else if (kind == 1) {              // PERM: 2x2 transpose of the 8-B units of each aligned 32-B pair
+            const int row = p >> 5, col = p & 31, c0 = col & ~1, e = col & 1;
+            *reinterpret_cast<uint2*>(slot + row * 512 + ((c0 ^ (row & 15)) << 4) + 8 * e) = make_uint2(r[q].x, r[q].y);
+            *reinterpret_cast<uint2*>(slot + row * 512 + (((c0 + 1) ^ (row & 15)) << 4) + 8 * e) = make_uint2(r[q].z, r[q].w);
+        } else {                             // 64-B rows, chunk index XOR ((row >> 2) & 3), PERM
+            const int row = p >> 2, col = p & 3, c0 = col & 2, e = col & 1, sw = (row >> 2) & 3;
+            *reinterpret_cast<uint2*>(slot + row * 64 + ((c0 ^ sw) << 4) + 8 * e) = make_uint2(r[q].x, r[q].y);
+            *reinterpret_cast<uint2*>(slot + row * 64 + (((c0 + 1) ^ sw) << 4) + 8 * e) = make_uint2(r[q].z, r[q].w);
+        }
+    }
+}
+
+// Two-slot weight ring (see the header comment) as macros over plain locals of the kernel (a struct holding the staging
+// registers ended up in scratch memory): `SRC(g)` maps the workgroup's g-th chunk to its WChunk; chunk indices are clamped
+// to the last one so that the loop body has no guards (the surplus copies at the very end are never read).
+//   RING_DECL(NT)                    locals: staging registers, chunk counter
+//   RING_START(smem, total, SRC)     first chunk into slot 0, second in flight
+//   RING_SYNC_WRITE(SRC)             barrier; chunk cc readable; chunk cc+1 written to the other slot
+//   RING_FETCH(SRC, slot)            chunk cc+2 goes in flight; `slot` = readable slot; ++cc
+#define RING_DECL(NTV) uint4 ring_r[1024 / (NTV)]; int ring_cc = 0, ring_last = 0; char* ring_smem = nullptr; constexpr int RING_NT = (NTV)
+#define RING_START(SMEM, TOTAL, SRC)                                                         \
+    do {                                                                                     \
+        ring_smem = (SMEM); ring_last = (TOTAL) - 1;                                         \
+        { const WChunk c0_ = SRC(0); stage_load<RING_NT>(ring_r, c0_, t); stage_write<RING_NT>(ring_r, c0_.kind, ring_smem, t); } \
+        { const WChunk c1_ = SRC(min(1, ring_last)); stage_load<RING_NT>(ring_r, c1_, t); }  \
+    } while (0)
+#define RING_SYNC_WRITE(SRC)                                                                 \
+    do {                                                                                     \
+        __syncthreads();                                                                     \
+        const WChunk cw_ = SRC(min(ring_cc + 1, ring_last));                                 \
+        stage_write<RING_NT>(ring_r, cw_.kind, ring_smem + ((ring_cc + 1) & 1) * CHUNK, t);  \
+    } while (0)
+#define RING_FETCH(SRC, SLOT)                                                                \
+    do {                                                                                     \
+        const WChunk cf_ = SRC(min(ring_cc + 2, ring_last));                                 \
+        stage_load<RING_NT>(ring_r, cf_, t);                                                 \
+        SLOT = ring_smem + (ring_cc & 1) * CHUNK;                                            \
+        ++ring_cc;                                                                           \
+    } while (0)
+#define RING_STEP(SRC, SLOT) do { RING_SYNC_WRITE(SRC); RING_FETCH(SRC, SLOT); } while (0)
+
+// weight operand of k-step S (0..15) from a [32][256] image: lane (i = lane & 31, h = lane >> 5)
+__device__ __forceinline__ opnd wfragA(const char* slot, int S, int i, int h) {
+    return as_opnd(*reinterpret_cast<const uint4*>(slot + i * 512 + (((2 * S + h) ^ (i & 15)) << 4)));
+}
+// weight operand of (tile t2 of 8, k-step s of 2) from a [256][32] image
+__device__ __forceinline__ opnd wfragB(const char* slot, int t2, int s, int i, int h) {
+    const int row = 32 * t2 + i;
+    return as_opnd(*reinterpret_cast<const uint4*>(slot + row * 64 + (((2 * s + h) ^ ((row >> 2) & 3)) << 4)));
+}
+
+__device__ __forceinline__ f32x16 mfma(opnd a, opnd b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// accumulator tile -> the two operands (k-steps) it provides to a product that sums over its n index
+__device__ __forceinline__ void acc_to_opnd(const f32x16& v, opnd& o0, opnd& o1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { o0[j] = (__bf16)v[j]; o1[j] = (__bf16)v[8 + j]; }
+}
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf2;
+    bf2 p; p[0] = (__bf16)a; p[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, p);
+}
+__device__ __forceinline__ float lo_f(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float hi_f(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// ---- accumulator-layout global I/O: lane (m, h) moves 16 B = features 32t + 16p + 8h .. +7 of its row, p = 0, 1
+// (`rowoff` = byte offset of the lane's row; rows beyond the tensor are dropped / read as zero by the bounds check)
+template <bool NTS>
+__device__ __forceinline__ void store_tile(const GBuf& b, uint32_t rowoff, int t, int h, const f32x16& v) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        uint32_t a0 = pack2(v[8 * p + 0], v[8 * p + 1]), a1 = pack2(v[8 * p + 2], v[8 * p + 3]);
+        uint32_t b0 = pack2(v[8 * p + 4], v[8 * p + 5]), b1 = pack2(v[8 * p + 6], v[8 * p + 7]);
+        auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        st16<NTS>(b, rowoff + 2 * (32 * t + 16 * p + 8 * h), make_uint4(r0[0], r1[0], r0[1], r1[1]));
+    }
+}
+struct RawTile { uint4 o[2]; };                 // a tile as loaded (lets the load be issued long before its use)
+__device__ __forceinline__ RawTile load_tile_raw(const GBuf& b, uint32_t rowoff, int t, int h) {
+    RawTile r;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) r.o[p] = ld16(b, rowoff + 2 * (32 * t + 16 * p + 8 * h));
+    return r;
+}
+__device__ __forceinline__ f32x16 tile_f32(const RawTile& rt) {
+    f32x16 v;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const uint4 o = rt.o[p];
+        auto r0 = __builtin_amdgcn_permlane32_swap(o.x, o.z, false, false);      // inverse of the store's exchange
+        auto r1 = __builtin_amdgcn_permlane32_swap(o.y, o.w, false, false);
+        v[8 * p + 0] = lo_f(r0[0]); v[8 * p + 1] = hi_f(r0[0]); v[8 * p + 2] = lo_f(r1[0]); v[8 * p + 3] = hi_f(r1[0]);
+        v[8 * p + 4] = lo_f(r0[1]); v[8 * p + 5] = hi_f(r0[1]); v[8 * p + 6] = lo_f(r1[1]); v[8 * p + 7] = hi_f(r1[1]);
+    }
+    return v;
+}
+__device__ __forceinline__ f32x16 load_tile(const GBuf& b, uint32_t rowoff, int t, int h) { return tile_f32(load_tile_raw(b, rowoff, t, h)); }
+// feature index of register r of tile t for lane half h
+__device__ __forceinline__ int feat(int t, int r, int h) { return 32 * t + 8 * (r >> 2) + 4 * h + (r & 3); }
+
+// v[r] += vec[feature]  (bias, kept in LDS): four 16-B reads per tile
+__device__ __forceinline__ void add_vec(f32x16& v, const float* vec, int t, int h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 b = *reinterpret_cast<const float4*>(vec + 32 * t + 8 * q + 4 * h);
+        v[4 * q + 0] += b.x; v[4 * q + 1] += b.y; v[4 * q + 2] += b.z; v[4 * q + 3] += b.w;
+    }
+}
+
+// workgroup copies a bias vector into LDS (zeros when there is none); caller synchronises
+__device__ __forceinline__ void stage_vec(float* dst, const float* src, int n, int t, int nthreads) {
+    for (int i = t; i < n; i += nthreads) dst[i] = src ? src[i] : 0.f;
+}
+
+__device__ __forceinline__ float xhalf(float v) { return v + __shfl_xor(v, 32); }   // row total: lanes m and m+32
+
+// ---- operand-layout (natural k order) row loads: lane (m, h) holds k = 16s + 8h + 0..7 of its row in x[s]
+template <int NS>
+__device__ __forceinline__ void load_rows(opnd (&x)[NS], const GBuf& b, uint32_t rowoff, int h) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) x[s] = as_opnd(ld16(b, rowoff + 2 * (16 * s + 8 * h)));
+}
+template <int NS>
+__device__ __forceinline__ void store_rows(const GBuf& b, uint32_t rowoff, int h, const opnd (&x)[NS]) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) st16<false>(b, rowoff + 2 * (16 * s + 8 * h), as_u4(x[s]));
+}
+__device__ __forceinline__ void unpack8f(opnd v, float* f) {
+    const uint4 w = as_u4(v);
+    f[0] = lo_f(w.x); f[1] = hi_f(w.x); f[2] = lo_f(w.y); f[3] = hi_f(w.y);
+    f[4] = lo_f(w.z); f[5] = hi_f(w.z); f[6] = lo_f(w.w); f[7] = hi_f(w.w);
+}
+__device__ __forceinline__ opnd pack8o(const float* f) {
+    opnd o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)f[j];
+    return o;
+}
+// LayerNorm without the affine part on a 256-wide row held as 16 operands: x <- (x - mean) * rstd; returns rstd.
+// (gamma is folded into the prepared weights and beta into the prepared bias: mmfm_prep_weights.)
+__device__ __forceinline__ float ln_rows(opnd (&x)[16], float eps) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float f[8]; unpack8f(x[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += f[j];
+    }
+    const float mu = xhalf(s) * (1.f / 256.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float f[8]; unpack8f(x[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = f[j] - mu; q += d * d; }
+    }
+    const float rs = rsqrtf(xhalf(q) * (1.f / 256.f) + eps);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float f[8]; unpack8f(x[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (f[j] - mu) * rs;
+        x[i] = pack8o(f);
+    }
+    return rs;
+}
+
+// ---- cheap exact-enough GELU for bf16 storage: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the
+// 2^-9 relative step of the bf16 value it feeds)
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = fmaf(-p, e, 1.f);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_fast(float x) {
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);      // exp(-x^2/2)
+    return 0.5f * (1.f + erf_as(x * 0.70710678118654752f)) + x * 0.39894228040143268f * e;
+}
+
+// 16 MFMAs of one [32][256] chunk against 16 operands, weight operands fetched 8 at a time (the ds_read latency of a
+// 2-deep fetch was 40 % of the loop: 830 cycles instead of 512 per chunk in the probe)
+__device__ __forceinline__ f32x16 mma16(const char* slot, const opnd* x, f32x16 acc, int m, int h) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        opnd wf[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) wf[s] = wfragA(slot, 8 * half + s, m, h);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc = mfma(wf[s], x[8 * half + s], acc);
+    }
+    return acc;
+}
+
+// ---- full-line global stores / loads through a per-wave LDS staging area -----------------------------------------------
+// In the accumulator (and the operand) layout only the two lanes m, m+32 hold data of row m, so a direct 16-B-per-lane
+// access touches 32 rows x 32 B per instruction.  Measured on MI355X (scripts/probe/rowchain_probe.hip): such partial-line
+// STORES issue at ~1.3 TB/s chip-wide and were 60 % of the first version's time.  Outputs therefore make one trip through
+// a 4 KB per-wave staging area [32 rows][128 B] (16-B chunk index XOR ((row >> 1) & 7): conflict-free both ways) and leave
+// as whole 128-B lines, 8 rows per instruction.  Same-wave LDS accesses execute in order: no barrier, no wait needed.
+constexpr int STG_BYTES = 4096;
+__device__ __forceinline__ int stg_off(int row, int c16) { return row * 128 + ((c16 ^ ((row >> 1) & 7)) << 4); }
+
+// accumulator tile -> staging columns 64*j .. 64*j+63 (bytes) of the wave's rows (j = 0, 1)
+__device__ __forceinline__ void stage_tile(char* stg, int j, int m, int h, const f32x16& v) {
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        uint32_t a0 = pack2(v[8 * p + 0], v[8 * p + 1]), a1 = pack2(v[8 * p + 2], v[8 * p + 3]);
+        uint32_t b0 = pack2(v[8 * p + 4], v[8 * p + 5]), b1 = pack2(v[8 * p + 6], v[8 * p + 7]);
+        auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        *reinterpret_cast<uint4*>(stg + stg_off(m, 4 * j + 2 * p + h)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+    }
+}
+// operand (natural k order) -> staging: operand s (0..3 within the 64-feature quarter)
+__device__ __forceinline__ void stage_opnd(char* stg, int s, int m, int h, opnd v) {
+    *reinterpret_cast<uint4*>(stg + stg_off(m, 2 * s + h)) = as_u4(v);
+}
+// staging -> global: rows wrow0 .. wrow0+31 of a tensor with `ldb` bytes per row, 128 bytes starting at byte column `colb`;
+// `nchunk` (1..8) = 16-B chunks of the 128 that exist (ragged last tile pair)
+template <bool NTS>
+__device__ __forceinline__ void flush_lines(const char* stg, const GBuf& b, uint32_t wrow0, uint32_t ldb, uint32_t colb, int lane, int nchunk = 8) {
+    const int c = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + (lane >> 3);
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + stg_off(row, c));
+        st16<NTS>(b, c < nchunk ? (wrow0 + row) * ldb + colb + 16 * c : 0xfffffff0u, v);
+    }
+}
+// global -> staging (whole lines), for later reads in either layout
+struct Lines { uint4 v[4]; };
+__device__ __forceinline__ Lines fetch_lines(const GBuf& b, uint32_t wrow0, uint32_t ldb, uint32_t colb, int lane) {
+    Lines L;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) L.v[i] = ld16(b, (wrow0 + 8 * i + (lane >> 3)) * ldb + colb + 16 * (lane & 7));
+    return L;
+}
+__device__ __forceinline__ void stage_lines(char* stg, const Lines& L, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(stg + stg_off(8 * i + (lane >> 3), lane & 7)) = L.v[i];
+}
+// staging -> accumulator-layout tile j (0, 1) in fp32
+__device__ __forceinline__ f32x16 unstage_tile(const char* stg, int j, int m, int h) {
+    RawTile rt;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) rt.o[p] = *reinterpret_cast<const uint4*>(stg + stg_off(m, 4 * j + 2 * p + h));
+    return tile_f32(rt);
+}
+__device__ __forceinline__ opnd unstage_opnd(const char* stg, int s, int m, int h) {
+    return as_opnd(*reinterpret_cast<const uint4*>(stg + stg_off(m, 2 * s + h)));
+}
+// a [32 rows][64*NQ features] block in operand layout -> global, whole lines (NQ quarters of 64 features)
+template <int NQ, bool NTS>
+__device__ __forceinline__ void store_rows_lines(char* stg, const GBuf& b, uint32_t wrow0, uint32_t ldb, int lane, int m, int h, const opnd (&x)[4 * NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) stage_opnd(stg, s, m, h, x[4 * q + s]);
+        flush_lines<NTS>(stg, b, wrow0, ldb, 128u * q, lane);
+    }
+}
+// global -> operand layout, whole lines: up to four quarters (64 registers) of loads in flight, transposed through the
+// staging area as they arrive
+template <int NQ>
+__device__ __forceinline__ void load_rows_lines(char* stg, opnd (&x)[4 * NQ], const GBuf& b, uint32_t wrow0, uint32_t ldb, int lane, int m, int h) {
+    constexpr int WIN = NQ < 4 ? NQ : 4;
+    Lines L[WIN];
+#pragma unroll
+    for (int q = 0; q < WIN; ++q) L[q] = fetch_lines(b, wrow0, ldb, 128u * q, lane);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        stage_lines(stg, L[q % WIN], lane);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) x[4 * q + s] = unstage_opnd(stg, s, m, h);
+        if (q + WIN < NQ) L[q % WIN] = fetch_lines(b, wrow0, ldb, 128u * (q + WIN), lane);
+    }
+}
+
+}  // namespace rowchain

@@ -1,0 +1,280 @@
+// mmfm_rowgemm / mmfm_prep_weights: row-owner GEMMs for the width-256 block linears (bf16 throughput mode).
+//   y[R][N] = epi( pro(x)[R][K] . W[N][K]^T ),  K = 256, 512 or 768, token rows owned by wavefronts (rowchain.h).
+// prologue : LayerNorm statistics + normalisation of the row in registers (K = 256; the affine part is folded into the
+//            prepared weights), with x_hat / rstd side outputs for the backward
+//            -> replaces nn.LayerNorm + the nn.Linear it feeds: ln1+qkv, query_norm+query, context_norm+key/value,
+//               encoder_norm+decoder_proj_context (encoder_embeddings.py:110-112, decoder_embeddings.py:139-143, mm.py:290-292)
+// epilogue : + bias, + residual, bf16 store  (attention out_proj + residual add, mm_utils.py:114 / encoder_embeddings.py:112)
+//        or  LayerNorm BACKWARD on the full output row (N = 256) + residual gradient: the dX product of a linear that
+//            was fed by a LayerNorm never writes d(x_hat) to memory (autograd of the sites above).
+#include "rowchain.h"
+#include <stdlib.h>
+#include <algorithm>
+
+using namespace rowchain;
+
+namespace {
+
+constexpr int NT = 256, NW = 4;
+
+// ------------------------------------------------------------------------------------------------ forward-type kernel
+constexpr int BIAS_MAX = 1024;                      // floats of bias kept in LDS behind the ring and the staging areas
+
+// NWV waves per workgroup (8 = two per SIMD wherever the registers allow: the barrier / LDS-write overhead of a chunk is
+// paid once per 256 rows instead of 128 and a SIMD's MFMA pipe is fed by two waves), 32 rows each
+template <int KP, bool LN, bool NTS, int NWV>
+__global__ __launch_bounds__(NWV * 64) void rowgemm_kernel(const mmfm_rowgemm_desc d) {
+    constexpr int NT = NWV * 64, NW = NWV;
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + NW * STG_BYTES + BIAS_MAX * 4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, m = lane & 31, h = lane >> 5;
+    const int npair = d.N >> 6, cpp = 2 * npair * KP;                   // N % 64 == 0
+    const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
+    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
+    if (my_passes == 0) return;
+    const uint16_t* W = reinterpret_cast<const uint16_t*>(d.w);
+    const int ldw = d.ldw;
+    // every workgroup walks the same weight tiles; each starts at a different tile pair
+    const int rot = d.rotate ? (int)(blockIdx.x % npair) : 0;
+    auto src = [=](int g) {
+        const int idx = g % cpp, ti = idx / KP, p = idx - ti * KP;
+        int pr = (ti >> 1) + rot; pr = pr >= npair ? pr - npair : pr;
+        WChunk c;
+        c.base = W + (size_t)(32 * (2 * pr + (ti & 1))) * ldw + 256 * p;
+        c.ld = ldw; c.kind = 0;
+        return c;
+    };
+    char* stg = smem + LDS_BYTES + wave * STG_BYTES;
+    float* lbias = reinterpret_cast<float*>(smem + LDS_BYTES + NW * STG_BYTES);
+    stage_vec(lbias, d.bias, d.N, t, NT);           // visible after the first chunk's barrier
+    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), RES = gbuf(d.residual, d.R * d.ldr * 2);
+    const GBuf XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4);
+    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2, ldrb = d.ldr * 2;
+    RING_DECL(NT);
+    RING_START(smem, my_passes * cpp, src);
+    for (int pi = 0; pi < my_passes; ++pi) {
+        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
+        const bool live = wrow0 < (uint32_t)d.R;          // wave-uniform: a wave without rows only keeps the ring's barriers
+        opnd x[16 * KP];
+        if (live) load_rows_lines<4 * KP>(stg, x, X, wrow0, ldxb, lane, m, h);
+        if constexpr (LN) if (live) {
+            const float rs = ln_rows(x, d.eps);
+            store_rows_lines<4, false>(stg, XH, wrow0, 512u, lane, m, h, x);
+            st4f(RS, h == 0 ? (wrow0 + m) * 4u : 0xfffffff0u, rs);
+        }
+        for (int tp = 0; tp < npair; ++tp) {
+            int pr = tp + rot; pr = pr >= npair ? pr - npair : pr;
+            f32x16 acc[2];
+            Lines res;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[j] = zero16();
+#pragma unroll
+                for (int p = 0; p < KP; ++p) {
+                    RING_SYNC_WRITE(src);
+                    if (j == 0 && p == 0) res = fetch_lines(RES, wrow0, ldrb, 128u * pr, lane);   // older than the chunk fetch
+                    const char* slot;
+                    RING_FETCH(src, slot);
+                    if (live) acc[j] = mma16(slot, x + 16 * p, acc[j], m, h);
+                }
+                add_vec(acc[j], lbias, 2 * pr + j, h);
+            }
+            if (!live) continue;
+            stage_lines(stg, res, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 r = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[j][i] += r[i];
+            }
+            stage_tile(stg, 0, m, h, acc[0]);
+            stage_tile(stg, 1, m, h, acc[1]);
+            flush_lines<NTS>(stg, Y, wrow0, ldyb, 128u * pr, lane);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dX + LayerNorm backward
+// v = x . W^T (N = 256: the gradient wrt x_hat of the LayerNorm that fed the forward linear; W = prepared W'^T);
+// y = dres + rstd * (v - mean(v) - x_hat * mean(v * x_hat))
+template <int KP>
+__global__ __launch_bounds__(NT) void rowgemm_lnbwd_kernel(const mmfm_rowgemm_desc d) {
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + NW * STG_BYTES];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, m = lane & 31, h = lane >> 5;
+    constexpr int cpp = 8 * KP;
+    const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
+    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
+    if (my_passes == 0) return;
+    const uint16_t* W = reinterpret_cast<const uint16_t*>(d.w);
+    const int ldw = d.ldw;
+    auto src = [=](int g) {
+        const int idx = g % cpp, tt = idx / KP, p = idx - tt * KP;
+        WChunk c;
+        c.base = W + (size_t)(32 * tt) * ldw + 256 * p;
+        c.ld = ldw; c.kind = 0;
+        return c;
+    };
+    char* stg = smem + LDS_BYTES + wave * STG_BYTES;
+    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), RES = gbuf(d.residual, d.R * d.ldr * 2);
+    const GBuf XH = gbuf(d.bwd_xhat, d.R * 512), RS = gbuf(d.bwd_rstd, d.R * 4);
+    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2, ldrb = d.ldr * 2;
+    RING_DECL(NT);
+    RING_START(smem, my_passes * cpp, src);
+    for (int pi = 0; pi < my_passes; ++pi) {
+        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
+        opnd x[16 * KP];
+        load_rows_lines<4 * KP>(stg, x, X, wrow0, ldxb, lane, m, h);
+        const float rs = ld4f(RS, (wrow0 + m) * 4u);
+        f32x16 acc[8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            Lines xl;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[2 * tp + j] = zero16();
+#pragma unroll
+                for (int p = 0; p < KP; ++p) {
+                    RING_SYNC_WRITE(src);
+                    if (j == 0 && p == 0) xl = fetch_lines(XH, wrow0, 512u, 128u * tp, lane);
+                    const char* slot;
+                    RING_FETCH(src, slot);
+                    acc[2 * tp + j] = mma16(slot, x + 16 * p, acc[2 * tp + j], m, h);
+                }
+            }
+            stage_lines(stg, xl, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 xt = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s1 += acc[2 * tp + j][i]; s2 = fmaf(acc[2 * tp + j][i], xt[i], s2); }
+            }
+        }
+        s1 = xhalf(s1) * (1.f / 256.f);
+        s2 = xhalf(s2) * (1.f / 256.f);
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            const Lines xl = fetch_lines(XH, wrow0, 512u, 128u * tp, lane);
+            const Lines rl = fetch_lines(RES, wrow0, ldrb, 128u * tp, lane);
+            stage_lines(stg, xl, lane);
+            f32x16 o[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 xt = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[j][i] = rs * (acc[2 * tp + j][i] - s1 - xt[i] * s2);
+            }
+            stage_lines(stg, rl, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 r = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[j][i] += r[i];
+            }
+            stage_tile(stg, 0, m, h, o[0]);
+            stage_tile(stg, 1, m, h, o[1]);
+            flush_lines<false>(stg, Y, wrow0, ldyb, 128u * tp, lane);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ weight preparation
+// One block per (entry, 32-row tile of W): Wp = bf16(W * gamma[k]) [N][K], WpT = its transpose [K][N],
+// bp[n] = bias[n] + sum_k W[n][k] * beta[k]  (the LayerNorm affine folded into the linear it feeds).
+__global__ __launch_bounds__(256) void prep_weights_kernel(const mmfm_prep_entry* __restrict__ E, int ne) {
+    __shared__ float tile[32][33];
+    int e = 0;
+    while (e + 1 < ne && (int)blockIdx.x >= E[e + 1].tile0) ++e;
+    const mmfm_prep_entry en = E[e];
+    const int n0 = ((int)blockIdx.x - en.tile0) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    uint16_t* Wp = reinterpret_cast<uint16_t*>(en.Wp);
+    uint16_t* WpT = reinterpret_cast<uint16_t*>(en.WpT);
+    float dot[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < en.K; k0 += 32) {
+        const int k = k0 + tx;
+        const float g = (en.gamma && k < en.K) ? en.gamma[k] : 1.f;
+        const float bt = (en.beta && k < en.K) ? en.beta[k] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + ty + 8 * j;
+            const float v = (n < en.N && k < en.K) ? en.W[(size_t)n * en.K + k] : 0.f;
+            const float w = v * g;
+            dot[j] = fmaf(v, bt, dot[j]);
+            if (Wp && n < en.N && k < en.K) Wp[(size_t)n * en.K + k] = f2bf(w);
+            tile[ty + 8 * j][tx] = w;
+        }
+        __syncthreads();
+        if (WpT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = k0 + ty + 8 * j, n = n0 + tx;
+                if (kk < en.K && n < en.N) WpT[(size_t)kk * en.N + n] = f2bf(tile[tx][ty + 8 * j]);
+            }
+        }
+        __syncthreads();
+    }
+    if (en.bp) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float r = dot[j];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) r += __shfl_xor(r, o);
+            const int n = n0 + ty + 8 * j;
+            if (tx == 0 && n < en.N) en.bp[n] = (en.bias ? en.bias[n] : 0.f) + r;
+        }
+    }
+}
+
+int grid_for(int64_t R, int per_cu, int nw = NW) {
+    const int64_t npass = (R + 32 * nw - 1) / (32 * nw);
+    return (int)std::max<int64_t>(1, std::min<int64_t>(npass, 256 * per_cu));
+}
+
+}  // namespace
+
+extern "C" int mmfm_rowgemm(const mmfm_rowgemm_desc* dp, mmfm_stream stream) {
+    const mmfm_rowgemm_desc d = *dp;
+    MMFM_REQUIRE(d.x && d.w && d.y && d.R > 0, "mmfm_rowgemm: null operand / empty problem");
+    MMFM_REQUIRE(d.K == 256 || d.K == 512 || d.K == 768, "mmfm_rowgemm: K = %d (256, 512 or 768 only)", d.K);
+    MMFM_REQUIRE(d.N > 0 && d.N % 64 == 0, "mmfm_rowgemm: N = %d must be a positive multiple of 64", d.N);
+    MMFM_REQUIRE(d.ldx % 8 == 0 && d.ldw % 8 == 0 && d.ldy % 8 == 0 && d.ldx >= d.K && d.ldw >= d.K && d.ldy >= d.N,
+                 "mmfm_rowgemm: leading dimensions (%d, %d, %d) must be multiples of 8 and cover the rows", d.ldx, d.ldw, d.ldy);
+    auto al16 = [](const void* p) { return ((uintptr_t)p & 15) == 0; };
+    MMFM_REQUIRE(al16(d.x) && al16(d.w) && al16(d.y) && al16(d.residual) && al16(d.xhat) && al16(d.bwd_xhat) && al16(d.bias),
+                 "mmfm_rowgemm: operands must be 16-byte aligned");
+    MMFM_REQUIRE(!d.residual || (d.ldr % 8 == 0 && d.ldr >= d.N), "mmfm_rowgemm: ldr %d", d.ldr);
+    MMFM_REQUIRE(!d.ln || d.K == 256, "mmfm_rowgemm: the LayerNorm prologue needs K = 256");
+    const int64_t maxld = std::max<int64_t>(std::max(d.ldx, d.ldy), std::max(d.ldr, 256));
+    MMFM_REQUIRE((d.R + 128) * maxld * 2 < (int64_t)1 << 31, "mmfm_rowgemm: tensors beyond 2 GiB are not addressable by the 32-bit buffer offsets");
+    MMFM_REQUIRE(d.N <= BIAS_MAX, "mmfm_rowgemm: N = %d > %d", d.N, BIAS_MAX);
+    static const int per_cu_env = [] { const char* e = getenv("MMFM_ROWGEMM_WG_PER_CU"); return e ? atoi(e) : 0; }();
+    hipStream_t st = (hipStream_t)stream;
+    if (d.ln_bwd) {
+        MMFM_REQUIRE(d.N == 256 && d.bwd_xhat && d.bwd_rstd && !d.ln && !d.bias, "mmfm_rowgemm: ln_bwd needs N = 256, x_hat, rstd, no bias/ln");
+        dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1)), block(NT);
+        if (d.K == 256) hipLaunchKernelGGL(rowgemm_lnbwd_kernel<1>, grid, block, 0, st, d);
+        else if (d.K == 512) hipLaunchKernelGGL(rowgemm_lnbwd_kernel<2>, grid, block, 0, st, d);
+        else hipLaunchKernelGGL(rowgemm_lnbwd_kernel<3>, grid, block, 0, st, d);
+    } else {
+        static const int nw_env = [] { const char* e = getenv("MMFM_ROWGEMM_WAVES"); return e ? atoi(e) : 0; }();
+        const int nw = d.K == 256 ? (nw_env == 4 ? 4 : 8) : 4;           // K = 256: 8 waves (<= 256 registers each)
+        dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, nw)), block(nw * 64);
+#define RG_LAUNCH(KP, LN, NWV)                                                                               \
+    if (d.stream_out) hipLaunchKernelGGL((rowgemm_kernel<KP, LN, true, NWV>), grid, block, 0, st, d);        \
+    else hipLaunchKernelGGL((rowgemm_kernel<KP, LN, false, NWV>), grid, block, 0, st, d);
+        if (d.ln) { if (nw == 8) { RG_LAUNCH(1, true, 8) } else { RG_LAUNCH(1, true, 4) } }
+        else if (d.K == 256) { if (nw == 8) { RG_LAUNCH(1, false, 8) } else { RG_LAUNCH(1, false, 4) } }
+        else if (d.K == 512) { RG_LAUNCH(2, false, 4) }
+        else { RG_LAUNCH(3, false, 4) }
+#undef RG_LAUNCH
+    }
+    MMFM_LAUNCH_CHECK("mmfm_rowgemm");
+    return 0;
+}
+
+extern "C" int mmfm_prep_weights(const mmfm_prep_entry* entries_dev, int n_entries, int total_tiles, mmfm_stream stream) {
+    MMFM_REQUIRE(entries_dev && n_entries > 0 && total_tiles > 0, "mmfm_prep_weights: empty table");
+    hipLaunchKernelGGL(prep_weights_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, entries_dev, n_entries);
+    MMFM_LAUNCH_CHECK("mmfm_prep_weights");
+    return 0;
+}

@@ -157,3 +157,60 @@ def rng_advance(state, plan=None):
 def collate_csr(B, max_T, max_N, pad_value, data, indices, indptr, indptr_off, nnz_off, T_b, N_b, out, tmask, smask, plan=None):
     _emit(plan, L.lib().mmfm_collate_csr, (B, max_T, max_N, float(pad_value), P(data), P(indices), P(indptr), P(indptr_off), P(nnz_off),
                                            P(T_b), P(N_b), P(out), P(tmask), P(smask)))
+
+
+# ---------------------------------------------------------------------------------------------- row-owner fused kernels
+def prep_table(entries, device):
+    """entries: dicts with W (fp32 [N,K]) and optional gamma, beta, bias, Wp, WpT, bp tensors -> (device table, n, tiles, keep)."""
+    import numpy as np
+    arr = (L.PrepEntry * len(entries))()
+    tile0 = 0
+    for i, e in enumerate(entries):
+        N, Kd = e["W"].shape
+        a = arr[i]
+        a.W, a.gamma, a.beta, a.bias = P(e["W"]), P(e.get("gamma")), P(e.get("beta")), P(e.get("bias"))
+        a.Wp, a.WpT, a.bp = P(e.get("Wp")), P(e.get("WpT")), P(e.get("bp"))
+        a.N, a.K, a.tile0 = N, Kd, tile0
+        tile0 += (N + 31) // 32
+    raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()
+    table = torch.from_numpy(raw).to(device)
+    return table, len(entries), tile0
+
+
+def prep_weights(table, n, tiles, plan=None):
+    _emit(plan, L.lib().mmfm_prep_weights, (P(table), n, tiles), keep=(table,))
+
+
+def rowgemm(x, w, y, R, N, K, *, ldx=None, ldw=None, ldy=None, bias=None, ln=False, eps=1e-5, xhat=None, rstd=None, residual=None,
+            ldr=0, stream_out=False, ln_bwd=False, bwd_xhat=None, bwd_rstd=None, rotate=True, plan=None):
+    d = L.RowGemmDesc()
+    d.R, d.K, d.N = R, K, N
+    d.x, d.ldx, d.w, d.ldw = P(x), K if ldx is None else ldx, P(w), K if ldw is None else ldw
+    d.bias, d.ln, d.eps, d.xhat, d.rstd = P(bias), int(ln), eps, P(xhat), P(rstd)
+    d.residual, d.ldr, d.y, d.ldy = P(residual), ldr, P(y), N if ldy is None else ldy
+    d.stream_out, d.ln_bwd, d.bwd_xhat, d.bwd_rstd, d.rotate = int(stream_out), int(ln_bwd), P(bwd_xhat), P(bwd_rstd), int(rotate)
+    _emit(plan, L.lib().mmfm_rowgemm, (C.byref(d),), keep=(d,))
+
+
+def mlp_desc(R, *, x=None, ldx=256, eps=1e-5, w_up=None, b_up=None, w_down=None, b_down=None, drop=None, y=None, ldy=256, xhat=None,
+             rstd=None, dy=None, lddy=256, w_down_t=None, w_up_t=None, t1=None, g=None, du=None, dx=None, lddx=256, rotate=True):
+    d = L.MlpDesc()
+    d.R, d.x, d.ldx, d.eps = R, P(x), ldx, eps
+    d.w_up, d.b_up, d.w_down, d.b_down = P(w_up), P(b_up), P(w_down), P(b_down)
+    d.drop = drop if drop is not None else L.NO_DROP
+    d.y, d.ldy, d.xhat, d.rstd = P(y), ldy, P(xhat), P(rstd)
+    d.dy, d.lddy, d.w_down_t, d.w_up_t = P(dy), lddy, P(w_down_t), P(w_up_t)
+    d.t1, d.g, d.du, d.dx, d.lddx, d.rotate = P(t1), P(g), P(du), P(dx), lddx, int(rotate)
+    return d
+
+
+def mlp_fwd(desc, plan=None):
+    _emit(plan, L.lib().mmfm_mlp_fwd, (C.byref(desc),), keep=(desc,))
+
+
+def mlp_bwd(desc, plan=None):
+    _emit(plan, L.lib().mmfm_mlp_bwd, (C.byref(desc),), keep=(desc,))
+
+
+def ln_linear_grad(Gdb, W, gamma, beta, N, K, dW, dbias, dgamma, dbeta, accumulate_ln=False, plan=None):
+    _emit(plan, L.lib().mmfm_ln_linear_grad, (P(Gdb), P(W), P(gamma), P(beta), N, K, P(dW), P(dbias), P(dgamma), P(dbeta), int(accumulate_ln)))

@@ -1,0 +1,204 @@
+"""Row-owner fused kernels (mmfm_prep_weights, mmfm_rowgemm, mmfm_mlp_fwd/bwd, mmfm_ln_linear_grad) against a torch
+fp64 reference of the same ops on the same bf16-rounded inputs.  bf16 storage: outputs carry one bf16 rounding
+(2^-9 relative) plus the rounding of in-kernel bf16 intermediates (x_hat, gelu output, du); tolerances are stated per check."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from multi_modal_foundation_model_amd import _lib as L, ops as K
+    L.check(L.lib().mmfm_device_check(0), "device_check")
+    return K
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30)), float((a - b).abs().max()), float(b.abs().max())
+
+
+def check(a, b, rel, msg):
+    r, mx, ref = relerr(a, b)
+    assert r < rel, f"{msg}: relative L2 error {r:.3e} (max abs {mx:.3e}, ref max {ref:.3e}) >= {rel}"
+
+
+def prep(ops, W, gamma=None, beta=None, bias=None, want_T=True):
+    N, K = W.shape
+    e = dict(W=W, gamma=gamma, beta=beta, bias=bias, Wp=torch.empty(N, K, device="cuda", dtype=BF),
+             WpT=torch.empty(K, N, device="cuda", dtype=BF) if want_T else None, bp=torch.empty(N, device="cuda"))
+    table, n, tiles = ops.prep_table([e], "cuda")
+    ops.prep_weights(table, n, tiles)
+    torch.cuda.synchronize()
+    return e
+
+
+def test_prep_weights_folds_layernorm_affine(ops):
+    W, g, b, bias = rnd(96, 256, seed=1), rnd(256, seed=2), rnd(256, seed=3), rnd(96, seed=4)
+    e = prep(ops, W, g, b, bias)
+    ref = (W * g).to(BF)
+    assert torch.equal(e["Wp"], ref) and torch.equal(e["WpT"], ref.T.contiguous())
+    torch.testing.assert_close(e["bp"], bias + W @ b, rtol=1e-5, atol=1e-5)
+    # several entries in one launch, ragged N
+    es = [dict(W=rnd(n, k, seed=9 + i), Wp=torch.empty(n, k, device="cuda", dtype=BF), WpT=torch.empty(k, n, device="cuda", dtype=BF))
+          for i, (n, k) in enumerate([(256, 512), (40, 256), (768, 256)])]
+    table, n, tiles = ops.prep_table(es, "cuda")
+    ops.prep_weights(table, n, tiles)
+    for e in es:
+        assert torch.equal(e["Wp"], e["W"].to(BF)) and torch.equal(e["WpT"], e["W"].to(BF).T.contiguous())
+
+
+@pytest.mark.parametrize("R,N,K", [(128, 256, 256), (1000, 768, 256), (4096 + 40, 512, 256), (300, 256, 512), (517, 256, 768), (33, 64, 256)])
+def test_rowgemm_plain(ops, R, N, K):
+    x, W, b = rnd(R, K, seed=1).to(BF), rnd(N, K, seed=2, scale=K ** -0.5).to(BF), rnd(N, seed=3)
+    res = rnd(R, N, seed=4).to(BF)
+    y = torch.full((R + 3, N), 7.0, device="cuda", dtype=BF)          # guard rows must stay untouched
+    ops.rowgemm(x, W, y, R, N, K, bias=b, residual=res, ldr=N)
+    ref = x.double() @ W.double().T + b.double() + res.double()
+    check(y[:R], ref, 4e-3, f"rowgemm {R}x{N}x{K}")
+    assert torch.all(y[R:] == 7.0)
+    ops.rowgemm(x, W, y, R, N, K, stream_out=True)
+    check(y[:R], x.double() @ W.double().T, 4e-3, f"rowgemm no-epilogue {R}x{N}x{K}")
+
+
+@pytest.mark.parametrize("R,N", [(256, 768), (1000, 256), (77, 512)])
+def test_rowgemm_layernorm_prologue(ops, R, N):
+    x = (rnd(R, 256, seed=1) * 2 + rnd(R, 1, seed=5) * 3).to(BF)       # non-zero row means
+    W, g, bt, bias = rnd(N, 256, seed=2, scale=1 / 16), 1 + 0.3 * rnd(256, seed=3), 0.2 * rnd(256, seed=4), rnd(N, seed=6)
+    e = prep(ops, W, g, bt, bias)
+    y, xhat, rstd = (torch.empty(R, N, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, device="cuda"))
+    res = rnd(R, N, seed=7).to(BF)
+    ops.rowgemm(x, e["Wp"], y, R, N, 256, bias=e["bp"], ln=True, xhat=xhat, rstd=rstd, residual=res, ldr=N)
+    xd = x.double()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    xh_ref = (xd - mu) / torch.sqrt(var + 1e-5)
+    check(xhat, xh_ref, 3e-3, "x_hat")
+    torch.testing.assert_close(rstd.double(), (1 / torch.sqrt(var + 1e-5)).squeeze(1), rtol=1e-5, atol=1e-6)
+    ref = F.layer_norm(xd, (256,), g.double(), bt.double(), 1e-5) @ W.double().T + bias.double() + res.double()
+    check(y, ref, 6e-3, f"ln+linear {R}x{N}")
+
+
+@pytest.mark.parametrize("R,K", [(300, 256), (1000, 768), (129, 512)])
+def test_rowgemm_layernorm_backward_epilogue(ops, R, K):
+    """dx = dres + LayerNorm'(dy . Wp) for a linear [K out-features] fed by a LayerNorm over 256."""
+    dy = rnd(R, K, seed=1).to(BF)
+    W, g = rnd(K, 256, seed=2, scale=K ** -0.5), 1 + 0.3 * rnd(256, seed=3)
+    x = rnd(R, 256, seed=4) * 1.7 + 0.5
+    dres = rnd(R, 256, seed=5).to(BF)
+    e = prep(ops, W, g, None, None)
+    mu, var = x.double().mean(1, keepdim=True), x.double().var(1, unbiased=False, keepdim=True)
+    rstd = (1 / torch.sqrt(var + 1e-5)).squeeze(1).float().contiguous()
+    xhat = ((x.double() - mu) * rstd.double()[:, None]).to(BF).contiguous()
+    dx = torch.empty(R, 256, device="cuda", dtype=BF)
+    ops.rowgemm(dy, e["WpT"], dx, R, 256, K, ldw=K, residual=dres, ldr=256, ln_bwd=True, bwd_xhat=xhat, bwd_rstd=rstd)
+    v = dy.double() @ e["Wp"].double()                                 # d x_hat
+    xh = xhat.double()
+    ref = dres.double() + rstd.double()[:, None] * (v - v.mean(1, keepdim=True) - xh * (v * xh).mean(1, keepdim=True))
+    check(dx, ref, 5e-3, f"ln-bwd epilogue {R}x{K}")
+
+
+def mlp_setup(ops, R, seed=0):
+    x = (rnd(R, 256, seed=seed + 1) * 1.5 + rnd(R, 1, seed=seed + 2)).to(BF)
+    Wu, bu = rnd(512, 256, seed=seed + 3, scale=1 / 16), 0.1 * rnd(512, seed=seed + 4)
+    Wd, bd = rnd(256, 512, seed=seed + 5, scale=1 / 22), 0.1 * rnd(256, seed=seed + 6)
+    g, bt = 1 + 0.3 * rnd(256, seed=seed + 7), 0.2 * rnd(256, seed=seed + 8)
+    up = prep(ops, Wu, g, bt, bu)
+    dn = prep(ops, Wd, None, None, bd)
+    return x, Wu, bu, Wd, bd, g, bt, up, dn
+
+
+@pytest.mark.parametrize("R", [128, 1000, 5000])
+def test_mlp_forward(ops, R):
+    x, Wu, bu, Wd, bd, g, bt, up, dn = mlp_setup(ops, R)
+    y, xhat, rstd = torch.full((R + 2, 256), 3.0, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, device="cuda")
+    d = ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd)
+    ops.mlp_fwd(d)
+    xd = x.double()
+    h = F.layer_norm(xd, (256,), g.double(), bt.double(), 1e-5)
+    ref = xd + F.gelu(h @ Wu.double().T + bu.double()) @ Wd.double().T + bd.double()
+    check(y[:R], ref, 6e-3, f"mlp fwd R={R}")
+    assert torch.all(y[R:] == 3.0)
+
+
+def test_mlp_forward_dropout_matches_backward_mask(ops):
+    """The forward's dropout mask (counter row*256 + col) is the one the backward regenerates: t1 = dropout'(dy) must be
+    zero exactly where y - x is zero, and scaled by 1/(1-p) elsewhere."""
+    R, p = 640, 0.4
+    x, Wu, bu, Wd, bd, g, bt, up, dn = mlp_setup(ops, R, seed=20)
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 5)
+    drop = ops.dropout(state, 9, p)
+    y, xhat, rstd = torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, device="cuda")
+    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd, drop=drop))
+    y0 = torch.empty_like(y)
+    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=y0, xhat=xhat, rstd=rstd))
+    kept = (y.float() - x.float()) != 0
+    assert 0.57 < kept.float().mean().item() < 0.63
+    ref = torch.where(kept, (y0.float() - x.float()) / (1 - p), torch.zeros((), device="cuda"))
+    big = ref.abs() > 0.5                                              # away from bf16 cancellation noise of y - x
+    torch.testing.assert_close((y.float() - x.float())[big], ref[big], rtol=0.05, atol=0.02)
+    dy = torch.ones(R, 256, device="cuda", dtype=BF)
+    t1, gg, du, dx = (torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 512, device="cuda", dtype=BF),
+                      torch.empty(R, 512, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF))
+    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], drop=drop, xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpT"],
+                             t1=t1, g=gg, du=du, dx=dx))
+    sure = (y0.float() - x.float()).abs() > 0.25                      # where "y == x" can only mean "dropped", not "rounded away"
+    assert sure.float().mean().item() > 0.3
+    torch.testing.assert_close(t1.float()[sure], (kept.float() / (1 - p))[sure], rtol=1e-2, atol=1e-2)
+    assert 0.57 < (t1 != 0).float().mean().item() < 0.63
+
+
+@pytest.mark.parametrize("R", [128, 1000])
+def test_mlp_backward(ops, R):
+    x, Wu, bu, Wd, bd, g, bt, up, dn = mlp_setup(ops, R, seed=40)
+    y, xhat, rstd = torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, device="cuda")
+    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd))
+    dy = rnd(R, 256, seed=77).to(BF)
+    t1, gg, du, dx = (torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 512, device="cuda", dtype=BF),
+                      torch.empty(R, 512, device="cuda", dtype=BF), torch.full((R + 1, 256), 5.0, device="cuda", dtype=BF))
+    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpT"],
+                             t1=t1, g=gg, du=du, dx=dx))
+    assert torch.equal(t1, dy) and torch.all(dx[R:] == 5.0)
+    xd = x.double().requires_grad_(True)
+    h = F.layer_norm(xd, (256,), g.double(), bt.double(), 1e-5)
+    u = h @ Wu.double().T + bu.double()
+    gl = F.gelu(u)
+    out = xd + gl @ Wd.double().T + bd.double()
+    u.retain_grad(); gl.retain_grad()
+    out.backward(dy.double())
+    check(gg, gl.detach(), 6e-3, "g")
+    check(du, u.grad, 1.2e-2, "du")
+    check(dx[:R], xd.grad, 1.2e-2, "dx")
+
+
+def test_ln_linear_grad_matches_autograd(ops):
+    """dW, db of the linear and dgamma, dbeta of the LayerNorm in front of it from G = dY^T x_hat and db = colsum dY."""
+    R, N, K = 700, 96, 256
+    x = (rnd(R, K, seed=1) * 1.3 + 0.4).double().requires_grad_(False)
+    W, bias, g, bt = (rnd(N, K, seed=2, scale=1 / 16).double().requires_grad_(True), rnd(N, seed=3).double().requires_grad_(True),
+                      (1 + 0.3 * rnd(K, seed=4)).double().requires_grad_(True), (0.2 * rnd(K, seed=5)).double().requires_grad_(True))
+    dY = rnd(R, N, seed=6).double()
+    y = F.layer_norm(x, (K,), g, bt, 1e-5) @ W.T + bias
+    y.backward(dY)
+    xhat = F.layer_norm(x, (K,), None, None, 1e-5)
+    Gdb = torch.cat([(dY.T @ xhat).flatten(), dY.sum(0)]).float().contiguous()
+    dW, db, dg, dbt = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda"), torch.ones(K, device="cuda"), torch.ones(K, device="cuda")
+    ops.ln_linear_grad(Gdb, W.detach().float().contiguous(), g.detach().float().contiguous(), bt.detach().float().contiguous(), N, K, dW, db, dg, dbt)
+    torch.testing.assert_close(dW.double(), W.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(db.double(), bias.grad, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(dg.double(), g.grad, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(dbt.double(), bt.grad, rtol=1e-4, atol=2e-4)
+    ops.ln_linear_grad(Gdb, W.detach().float().contiguous(), g.detach().float().contiguous(), bt.detach().float().contiguous(), N, K, dW, db, dg, dbt,
+                       accumulate_ln=True)
+    torch.testing.assert_close(dg.double(), 2 * g.grad, rtol=1e-4, atol=4e-4)
