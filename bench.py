@@ -18,7 +18,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "multi_modal_foundation_model_amd", "src"), os.path.join(ROOT, "tests")):
+for p in (ROOT, os.path.join(ROOT, "multi_modal_foundation_model_amd", "src")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -86,6 +86,14 @@ def kernel_profile(engine, plan, reps=3):
             d = keep[0]
             flops = 2.0 * d.M * d.N * d.K
             sub = "x.W^T" if (d.a_kcontig and d.b_kcontig) else ("dY.W" if d.a_kcontig else "dY^T.X")
+        elif name == "mmfm_rowgemm":
+            d = keep[0]
+            flops = 2.0 * d.R * d.N * d.K
+            sub = "row dX (+LN bwd)" if d.ln_bwd else ("row LN+x.W^T" if d.ln else ("row x.W^T" if d.bias else "row dY.W"))
+        elif name in ("mmfm_mlp_fwd", "mmfm_mlp_bwd"):
+            d = keep[0]
+            flops = 4.0 * d.R * 256 * 512           # algorithmic: two products each way (the backward's recompute of up() is not counted)
+            sub = "row MLP fwd" if name.endswith("fwd") else "row MLP bwd (dX chain)"
         elif name in ("mmfm_attn_fwd", "mmfm_attn_bwd"):
             d = keep[0]
             flops = (4.0 if name.endswith("fwd") else 10.0) * d.B * d.heads * d.Lq * d.Lk * d.dh
@@ -162,7 +170,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from helpers import build_model, load_config
+    from multi_modal_foundation_model_amd.builders import build_model, load_config
     from torch.optim.lr_scheduler import OneCycleLR
     from multi_modal_foundation_model_amd.ddp import DataParallelModel
     from multi_modal_foundation_model_amd.optim import make_optimizer
@@ -259,14 +267,21 @@ def main():
             res["kernel_breakdown_ms"] = {k: round(v[1], 3) for k, v in top[:8]}
             res["gemm_layouts"] = {k: dict(launches=v[0], ms=round(v[1], 3), tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1)) for k, v in subs.items()}
             res["kernel_time_sum_ms"] = round(tot, 3)
-            mf = [(k, v) for k, v in top if v[2] > 0]
-            k, v = mf[0]
+            # dominant kernel family = the dense linears (every nn.Linear forward / dX / dW product of the step): the generic tiled
+            # GEMM plus the row-owner fused kernels that absorbed LayerNorm / GELU / residual work
+            FAM = ("mmfm_gemm", "mmfm_rowgemm", "mmfm_mlp_fwd", "mmfm_mlp_bwd")
+            fam = [agg[n] for n in FAM if n in agg]
+            v = [sum(x[0] for x in fam), sum(x[1] for x in fam), sum(x[2] for x in fam)]
+            k = "dense linears: " + "+".join(n for n in FAM if n in agg)
+            res["family_ms"] = {n: round(agg[n][1], 3) for n in FAM if n in agg}
             achieved = v[2] / (v[1] * 1e-3) / 1e12
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):
                 with open(tpath) as f:
-                    traffic = json.load(f).get(k)
+                    tj = json.load(f)
+                    if all(n in tj for n in FAM if n in agg):
+                        traffic = int(sum(tj[n] * agg[n][0] for n in FAM if n in agg) / max(1, v[0]))
             res["roofline"] = dict(bound="mfma", kernel=k, launches_per_step=v[0], achieved=round(achieved, 2),
                                    peak=PEAK_TFLOPS[a.dtype], unit="TFLOP/s", frac=round(achieved / PEAK_TFLOPS[a.dtype], 4),
                                    traffic=traffic, avg_launch_ms=round(v[1] / v[0], 4),

@@ -295,6 +295,57 @@ class Engine:
     def _drop(self, key, p):
         return K.dropout(self.rng, self._site(key), p) if p > 0 else None
 
+    # ------------------------------------------------------------------ row-owner fused path (bf16, width 256 / 512)
+    def _fused_mask(self, R):
+        """Which op groups run as row-owner fused kernels (csrc/rowchain.h): bit 0 ln1+qkv, bit 1 the other LayerNorm-fed
+        linears (cross-attention query / key-value, decoder_proj_context), bit 2 the MLP block, bit 3 attention out_proj.
+        MMFM_FUSED overrides (0 = the un-fused kernels of round 1)."""
+        c = self.cfg
+        if self.dtype != "bf16" or c.hidden != 256 or c.inter != 512 or (R + 128) * 1024 * 2 >= 2 ** 31:
+            return 0
+        return int(os.environ.get("MMFM_FUSED", "15")) & 15
+
+    def _build_prep(self):
+        """Prepared weights of the fused path: per LayerNorm-fed linear Wp = bf16(W * gamma), WpT, bp = b + W beta
+        (mmfm_prep_weights); per plain linear only the bf16 transpose (the dX products read K-contiguous rows)."""
+        if getattr(self, "_prep", None) is not None:
+            return self._prep
+        c = self.cfg
+        sites = []
+        for i in range(c.n_enc):
+            p = f"encoder.{i}"
+            sites += [(p + ".attn.qkv", p + ".ln1"), (p + ".attn.out_proj", None), (p + ".mlp.up_proj", p + ".ln2"), (p + ".mlp.down_proj", None)]
+        sites.append(("decoder_proj_context", "encoder_norm"))
+        for i in range(c.n_dec):
+            p = f"decoder.{i}"
+            sites += [(p + ".attn.qkv", p + ".ln1"), (p + ".attn.out_proj", None), (p + ".cross_attn.query", p + ".query_norm"),
+                      (p + ".cross_attn.kv", p + ".context_norm"), (p + ".cross_attn.out_proj", None), (p + ".mlp.up_proj", p + ".ln2"),
+                      (p + ".mlp.down_proj", None)]
+        nW = sum(self.Pf(w + ".weight").numel() for w, _ in sites)
+        nWp = sum(self.Pf(w + ".weight").numel() for w, ln in sites if ln)
+        nb = sum(self.Pf(w + ".bias").numel() for w, ln in sites if ln)
+        WpT = torch.zeros(nW + 64, dtype=torch.bfloat16, device=self.device)
+        Wp = torch.zeros(nWp + 64, dtype=torch.bfloat16, device=self.device)
+        bp = torch.zeros(nb + 64, dtype=torch.float32, device=self.device)
+        views, entries, oT, oW, ob = {}, [], 0, 0, 0
+        for w, ln in sites:
+            Wm = self.Pf(w + ".weight")
+            N, Kd = Wm.shape
+            e = dict(W=Wm, WpT=WpT[oT:oT + N * Kd].view(Kd, N))
+            oT += N * Kd
+            v = dict(WpT=e["WpT"])
+            if ln:
+                e.update(gamma=self.Pf(ln + ".weight"), beta=self.Pf(ln + ".bias"), bias=self.Pf(w + ".bias"),
+                         Wp=Wp[oW:oW + N * Kd].view(N, Kd), bp=bp[ob:ob + N])
+                oW += N * Kd
+                ob += N
+                v.update(Wp=e["Wp"], bp=e["bp"])
+            views[w] = v
+            entries.append(e)
+        table, n, tiles = K.prep_table(entries, self.device)
+        self._prep = dict(table=table, n=n, tiles=tiles, v=views, keep=(WpT, Wp, bp, entries))
+        return self._prep
+
     # ------------------------------------------------------------------ plan construction
     def _dw_split(self, M, N, R):
         """Split-K factor for a dW GEMM ([M,N] output, reduction over R tokens): tiles x splits fills the persistent
@@ -308,8 +359,9 @@ class Engine:
         kchunk = _align(-(-R // S), 64)          # multiple of both kernels' BK (32 fp32, 64 bf16)
         return -(-R // kchunk), kchunk
 
-    def _plan(self, B, T, training):
-        key = (B, T, bool(training))
+    def _plan(self, B, T, training, grad=True):
+        """grad = False: a forward-only plan (evaluation under no_grad) that skips the tensors saved for the backward."""
+        key = (B, T, bool(training), bool(grad))
         self._select_pool(B, T)
         if key in self.plans:
             return self.plans[key]
@@ -399,6 +451,42 @@ class Engine:
                                dk=None if dkv is None else dkv.data_ptr() + dkoff * es,
                                dv=None if dkv is None else dkv.data_ptr() + dvoff * es, lddq=lddq, lddk=lddkv, lddv=lddkv)
 
+        fm = self._fused_mask(R)
+        F_QKV, F_LNL, F_MLP, F_OUT = bool(fm & 1), bool(fm & 2), bool(fm & 4), bool(fm & 8)
+        prep = self._build_prep() if fm else None
+        if fm:
+            K.prep_weights(prep["table"], prep["n"], prep["tiles"], plan=fwd)
+            gdb = buf("ws/gdb", (max(_align(mm * nn + mm) for mm, nn in ((3 * H, H), (2 * H, H), (I, H), (H, H))),), f32)
+
+        def ln_lin(plan, Xin, lnname, wname, Yout, N, tag, residual=None):
+            """LayerNorm + the linear it feeds in one launch; x_hat / rstd saved for the backward when training."""
+            pw = prep["v"][wname]
+            xh = buf(tag + "/xh", (R, H)) if grad else None
+            rs = buf(tag + "/rs", (R,), f32) if grad else None
+            K.rowgemm(Xin, pw["Wp"], Yout, R, N, H, bias=pw["bp"], ln=True, xhat=xh, rstd=rs, residual=residual,
+                      ldr=H if residual is not None else 0, stream_out=True, plan=plan)
+
+        def dlin_ln(plan, dYt, tag, wname, lnname, N):
+            """Gradients of a LayerNorm-fed linear and of that LayerNorm's affine from G = dY^T x_hat (mmfm_ln_linear_grad)."""
+            S, kchunk = self._dw_split(N, H, R)
+            xh = self.b[tag + "/xh"]
+            if S == 1:
+                K.gemm(dYt, xh, gdb, N, H, R, lda=N, ldb=H, ldc=H, a_kcontig=0, b_kcontig=0, dtype=code, c_f32=1,
+                       colsum=gdb.data_ptr() + 4 * N * H, plan=plan)
+            else:
+                stride = _align(N * H + N)
+                K.gemm(dYt, xh, slab, N, H, R, lda=N, ldb=H, ldc=H, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
+                       slab_stride=stride, dtype=code, c_f32=1, colsum=slab.data_ptr() + 4 * N * H, plan=plan)
+                K.reduce_slabs(gdb, slab, N * H + N, S, stride, plan=plan)
+            K.ln_linear_grad(gdb, self.Pf(wname + ".weight"), self.Pf(lnname + ".weight"), self.Pf(lnname + ".bias"), N, H,
+                             self.Gv(wname + ".weight"), self.Gv(wname + ".bias"), self.Gv(lnname + ".weight"), self.Gv(lnname + ".bias"),
+                             plan=plan)
+
+        def dx_ln(plan, dYt, Kd, tag, wname, dres, dXout):
+            """dX of a LayerNorm-fed linear with the LayerNorm backward (and the residual gradient) in its epilogue."""
+            K.rowgemm(dYt, prep["v"][wname]["WpT"], dXout, R, H, Kd, ldw=Kd, residual=dres, ldr=H if dres is not None else 0,
+                      ln_bwd=True, bwd_xhat=self.b[tag + "/xh"], bwd_rstd=self.b[tag + "/rs"], plan=plan)
+
         enc_flags = L.ATTN_DIAG                                                # mm.py:152-158
         dec_flags = (L.ATTN_CAUSAL if c.causal_mask else 0) | (L.ATTN_SEP if c.sep_mask else 0)   # mm.py:178-194
 
@@ -417,18 +505,38 @@ class Engine:
                 mod_row = self.Pf(f"encoder_embeddings.{mod}.embedder.mod_emb.weight")[m]
                 K.stitch_fwd(tok_tmp, mod_row, self.Pf(p + ".pos_embed.weight"), ts, keep0, xs, es_, B, T, Lq, m, H, c.max_F, plan=fwd)
 
+        def out_proj(plan, a, wname, Xres, Xout):
+            if F_OUT:
+                K.rowgemm(a, self.W(wname + ".weight"), Xout, R, H, H, bias=self.Pf(wname + ".bias"), residual=Xres, ldr=H, plan=plan)
+            else:
+                lin(plan, a, wname, Xout, R, H, H, residual=Xres, ldr=H)
+
         def self_block(plan, X, p, tag, flags):
             """x + attn(ln1(x))  (encoder_embeddings.py:112, decoder_embeddings.py:141)."""
-            h, qkv, a, Xa = buf(tag + "/h1", (R, H)), buf(tag + "/qkv", (R, 3 * H)), buf(tag + "/a", (R, H)), buf(tag + "/xa", (R, H))
-            ln_f(plan, X, p + ".ln1", h, tag + "/ln1")
-            lin(plan, h, p + ".attn.qkv", qkv, R, 3 * H, H)
+            qkv, a, Xa = buf(tag + "/qkv", (R, 3 * H)), buf(tag + "/a", (R, H)), buf(tag + "/xa", (R, H))
+            if F_QKV:
+                ln_lin(plan, X, p + ".ln1", p + ".attn.qkv", qkv, 3 * H, tag + "/ln1")
+            else:
+                h = buf(tag + "/h1", (R, H))
+                ln_f(plan, X, p + ".ln1", h, tag + "/ln1")
+                lin(plan, h, p + ".attn.qkv", qkv, R, 3 * H, H)
             K.attn_fwd(attn_desc(tag + "/sa", qkv, 3 * H, qkv, 3 * H, H, 2 * H, a, flags), plan=plan)
-            lin(plan, a, p + ".attn.out_proj", Xa, R, H, H, residual=X, ldr=H)
+            out_proj(plan, a, p + ".attn.out_proj", X, Xa)
             return Xa
+
 
         def mlp_block(plan, X, p, tag):
             """x + mlp(ln2(x))  (encoder_embeddings.py:114; mm_utils.py:50-52)."""
-            h, u, g, Xb = buf(tag + "/h2", (R, H)), buf(tag + "/u", (R, I)), buf(tag + "/g", (R, I)), buf(tag + "/xb", (R, H))
+            Xb = buf(tag + "/xb", (R, H))
+            if F_MLP:
+                pu = prep["v"][p + ".mlp.up_proj"]
+                d_ = K.mlp_desc(R, x=X, w_up=pu["Wp"], b_up=pu["bp"], w_down=self.W(p + ".mlp.down_proj.weight"),
+                                b_down=self.Pf(p + ".mlp.down_proj.bias"), drop=self._drop(tag + "/mlpdrop", dp), y=Xb,
+                                xhat=buf(tag + "/ln2/xh", (R, H)) if grad else None,
+                                rstd=buf(tag + "/ln2/rs", (R,), f32) if grad else None)
+                K.mlp_fwd(d_, plan=plan)
+                return Xb
+            h, u, g = buf(tag + "/h2", (R, H)), buf(tag + "/u", (R, I)), buf(tag + "/g", (R, I))
             ln_f(plan, X, p + ".ln2", h, tag + "/ln2")
             lin(plan, h, p + ".mlp.up_proj", g, R, I, H, pre_out=u, act=L.ACT_GELU)
             lin(plan, g, p + ".mlp.down_proj", Xb, R, H, I, drop=self._drop(tag + "/mlpdrop", dp), residual=X, ldr=H)
@@ -443,21 +551,28 @@ class Engine:
             X = mlp_block(fwd, Xa, p, tag)
         enc_last = X
         enc_out, context = buf("enc_out", (R, H)), buf("context", (R, H))
-        ln_f(fwd, X, "encoder_norm", enc_out, "encnorm")
-        lin(fwd, enc_out, "decoder_proj_context", context, R, H, H, residual=emb_enc, ldr=H)       # mm.py:292
+        if F_LNL:
+            ln_lin(fwd, X, "encoder_norm", "decoder_proj_context", context, H, "encnorm", residual=emb_enc)
+        else:
+            ln_f(fwd, X, "encoder_norm", enc_out, "encnorm")
+            lin(fwd, enc_out, "decoder_proj_context", context, R, H, H, residual=emb_enc, ldr=H)       # mm.py:292
         Y = x_dec
         for i in range(c.n_dec):
             p, tag = f"decoder.{i}", f"dec{i}"
             stream_in[tag] = Y
             Ya = self_block(fwd, Y, p, tag, dec_flags)
-            hq, hc = buf(tag + "/hq", (R, H)), buf(tag + "/hc", (R, H))
             qc, kvc, a2, Yb = buf(tag + "/qc", (R, H)), buf(tag + "/kvc", (R, 2 * H)), buf(tag + "/a2", (R, H)), buf(tag + "/yb", (R, H))
-            ln_f(fwd, Ya, p + ".query_norm", hq, tag + "/qn")
-            ln_f(fwd, context, p + ".context_norm", hc, tag + "/cn")
-            lin(fwd, hq, p + ".cross_attn.query", qc, R, H, H)
-            lin(fwd, hc, p + ".cross_attn.kv", kvc, R, 2 * H, H)
+            if F_LNL:
+                ln_lin(fwd, Ya, p + ".query_norm", p + ".cross_attn.query", qc, H, tag + "/qn")
+                ln_lin(fwd, context, p + ".context_norm", p + ".cross_attn.kv", kvc, 2 * H, tag + "/cn")
+            else:
+                hq, hc = buf(tag + "/hq", (R, H)), buf(tag + "/hc", (R, H))
+                ln_f(fwd, Ya, p + ".query_norm", hq, tag + "/qn")
+                ln_f(fwd, context, p + ".context_norm", hc, tag + "/cn")
+                lin(fwd, hq, p + ".cross_attn.query", qc, R, H, H)
+                lin(fwd, hc, p + ".cross_attn.kv", kvc, R, 2 * H, H)
             K.attn_fwd(attn_desc(tag + "/xa", qc, H, kvc, 2 * H, 0, H, a2, enc_flags), plan=fwd)   # xa_mask = encoder mask
-            lin(fwd, a2, p + ".cross_attn.out_proj", Yb, R, H, H, residual=Ya, ldr=H)
+            out_proj(fwd, a2, p + ".cross_attn.out_proj", Ya, Yb)
             Y = mlp_block(fwd, Yb, p, tag)
         dec_last = Y
         ydec = buf("ydec", (R, H))                         # de-stitched: [M][B*T][H]
@@ -469,6 +584,10 @@ class Engine:
                               ws_loss, plan=fwd)
         K.loss_finalize(loss_sum, count, M, self.b["loss"], self.b["inv_n"], plan=fwd)
 
+        if not grad:
+            plan = dict(fwd=fwd, bwd=None, B=B, T=T, training=bool(training), M=M, R=R, BT=BT, runs=dict(fwd=0, bwd=0), graphs={}, b=self.b)
+            self.plans[key] = plan
+            return plan
         # ============================================================ backward (segments fire DDP hooks)
         bwd: List[Tuple[str, list]] = []
         cur: list = []
@@ -492,6 +611,15 @@ class Engine:
 
         def mlp_back(plan, dS, p, tag, X_in):
             """dS: running gradient of the residual stream (in place).  X_in = the stream value that fed ln2."""
+            if F_MLP:
+                pu, pdn = prep["v"][p + ".mlp.up_proj"], prep["v"][p + ".mlp.down_proj"]
+                t1b, gb, dub = buf("d/t1m", (R, H)), buf("d/g", (R, I)), buf("d/du", (R, I))
+                d_ = K.mlp_desc(R, w_up=pu["Wp"], b_up=pu["bp"], drop=self._drop(tag + "/mlpdrop", dp), xhat=self.b[tag + "/ln2/xh"],
+                                rstd=self.b[tag + "/ln2/rs"], dy=dS, w_down_t=pdn["WpT"], w_up_t=pu["WpT"], t1=t1b, g=gb, du=dub, dx=dS)
+                K.mlp_bwd(d_, plan=plan)
+                dlin(plan, t1b, gb, p + ".mlp.down_proj", R, H, I)          # dW_down = t1^T g, db_down = colsum t1
+                dlin_ln(plan, dub, tag + "/ln2", p + ".mlp.up_proj", p + ".ln2", I)
+                return
             dSd = dS
             if dp > 0:                                                       # mm_utils.py:52 dropout(down_proj(.))
                 K.dropout_apply(dS, t1, R, H, self._drop(tag + "/mlpdrop", dp), plan=plan)
@@ -500,13 +628,25 @@ class Engine:
             dlin(plan, du, self.b[tag + "/h2"], p + ".mlp.up_proj", R, I, H, dX=dh_)
             ln_b(plan, dh_, X_in, p + ".ln2", tag + "/ln2", dS, dS)
 
+        def out_proj_back(plan, dS, a, wname):
+            """dW, db of an attention out_proj and d(attention output) -> t2."""
+            if F_OUT:
+                dlin(plan, dS, a, wname, R, H, H)
+                K.rowgemm(dS, prep["v"][wname]["WpT"], t2, R, H, H, plan=plan)
+            else:
+                dlin(plan, dS, a, wname, R, H, H, dX=t2)
+
         def self_back(plan, dS, p, tag, X_in, flags):
-            dlin(plan, dS, self.b[tag + "/a"], p + ".attn.out_proj", R, H, H, dX=t2)
+            out_proj_back(plan, dS, self.b[tag + "/a"], p + ".attn.out_proj")
             qkv = self.b[tag + "/qkv"]
             K.attn_bwd(attn_desc(tag + "/sa", qkv, 3 * H, qkv, 3 * H, H, 2 * H, self.b[tag + "/a"], flags, d_o=t2, dq=dqkv, dkv=dqkv,
                                  lddq=3 * H, lddkv=3 * H, dkoff=H, dvoff=2 * H), plan=plan)
-            dlin(plan, dqkv, self.b[tag + "/h1"], p + ".attn.qkv", R, 3 * H, H, dX=dh_)
-            ln_b(plan, dh_, X_in, p + ".ln1", tag + "/ln1", dS, dS)
+            if F_QKV:
+                dlin_ln(plan, dqkv, tag + "/ln1", p + ".attn.qkv", p + ".ln1", 3 * H)
+                dx_ln(plan, dqkv, 3 * H, tag + "/ln1", p + ".attn.qkv", dS, dS)
+            else:
+                dlin(plan, dqkv, self.b[tag + "/h1"], p + ".attn.qkv", R, 3 * H, H, dX=dh_)
+                ln_b(plan, dh_, X_in, p + ".ln1", tag + "/ln1", dS, dS)
 
         dqc, dkvc = buf("d/qc", (R, H)), buf("d/kvc", (R, 2 * H))
         first_ctx = True
@@ -514,13 +654,19 @@ class Engine:
             p, tag = f"decoder.{i}", f"dec{i}"
             mlp_back(cur, dY, p, tag, self.b[tag + "/yb"])
             # cross attention (decoder_embeddings.py:143): query side -> stream, context side -> dctx
-            dlin(cur, dY, self.b[tag + "/a2"], p + ".cross_attn.out_proj", R, H, H, dX=t2)
+            out_proj_back(cur, dY, self.b[tag + "/a2"], p + ".cross_attn.out_proj")
             K.attn_bwd(attn_desc(tag + "/xa", self.b[tag + "/qc"], H, self.b[tag + "/kvc"], 2 * H, 0, H, self.b[tag + "/a2"], enc_flags,
                                  d_o=t2, dq=dqc, dkv=dkvc, lddq=H, lddkv=2 * H, dkoff=0, dvoff=H), plan=cur)
-            dlin(cur, dqc, self.b[tag + "/hq"], p + ".cross_attn.query", R, H, H, dX=dh_)
-            ln_b(cur, dh_, self.b[tag + "/xa"], p + ".query_norm", tag + "/qn", dY, dY)
-            dlin(cur, dkvc, self.b[tag + "/hc"], p + ".cross_attn.kv", R, 2 * H, H, dX=dh_)
-            ln_b(cur, dh_, context, p + ".context_norm", tag + "/cn", None if first_ctx else dctx, dctx)
+            if F_LNL:
+                dlin_ln(cur, dqc, tag + "/qn", p + ".cross_attn.query", p + ".query_norm", H)
+                dx_ln(cur, dqc, H, tag + "/qn", p + ".cross_attn.query", dY, dY)
+                dlin_ln(cur, dkvc, tag + "/cn", p + ".cross_attn.kv", p + ".context_norm", 2 * H)
+                dx_ln(cur, dkvc, 2 * H, tag + "/cn", p + ".cross_attn.kv", None if first_ctx else dctx, dctx)
+            else:
+                dlin(cur, dqc, self.b[tag + "/hq"], p + ".cross_attn.query", R, H, H, dX=dh_)
+                ln_b(cur, dh_, self.b[tag + "/xa"], p + ".query_norm", tag + "/qn", dY, dY)
+                dlin(cur, dkvc, self.b[tag + "/hc"], p + ".cross_attn.kv", R, 2 * H, H, dX=dh_)
+                ln_b(cur, dh_, context, p + ".context_norm", tag + "/cn", None if first_ctx else dctx, dctx)
             first_ctx = False
             self_back(cur, dY, p, tag, stream_in[tag], dec_flags)
             close_segment(p)
@@ -528,8 +674,12 @@ class Engine:
             raise NotImplementedError("n_dec == 0")
         # now dY = d(dec_tokens + dec_emb) and dctx = d(context); context = ctx_proj(enc_out) + encoder_emb (mm.py:292)
         dX = buf("d/xstream", (R, H))
-        dlin(cur, dctx, enc_out, "decoder_proj_context", R, H, H, dX=dh_)
-        ln_b(cur, dh_, enc_last, "encoder_norm", "encnorm", None, dX)
+        if F_LNL:
+            dlin_ln(cur, dctx, "encnorm", "decoder_proj_context", "encoder_norm", H)
+            dx_ln(cur, dctx, H, "encnorm", "decoder_proj_context", None, dX)
+        else:
+            dlin(cur, dctx, enc_out, "decoder_proj_context", R, H, H, dX=dh_)
+            ln_b(cur, dh_, enc_last, "encoder_norm", "encnorm", None, dX)
         close_segment("bridge")
         for i in reversed(range(c.n_enc)):
             p, tag = f"encoder.{i}", f"enc{i}"
@@ -585,7 +735,8 @@ class Engine:
 
     # ------------------------------------------------------------------ run
     def forward(self, B, T, inputs, targets, masks, ts, attn, training=True, anchor=None):
-        plan = self._plan(B, T, training)
+        want_grad = anchor is not None and torch.is_grad_enabled() and anchor.requires_grad
+        plan = self._plan(B, T, training, want_grad)
         self.load_inputs(B, T, inputs, targets, masks, ts, attn)
         advance = training and (self.cfg.dropout > 0 or self.cfg.embed_dropout > 0)
 
@@ -602,7 +753,7 @@ class Engine:
         out = dict(mod_loss=[self.b["loss_sum"][m].clone() for m in range(M)],
                    mod_n=[self.b["count"][m].clone() for m in range(M)],
                    preds=[self.b[f"pred/{m}"].view(B, T, -1) for m in range(M)])
-        if anchor is not None and torch.is_grad_enabled() and anchor.requires_grad:
+        if want_grad:
             out["loss"] = _StepFn.apply(anchor, self, self._token)
         else:
             out["loss"] = self.b["loss"].clone().reshape(())
@@ -621,6 +772,8 @@ class Engine:
         if first is not None and first.grad is not None:
             accumulate_into = self.G.clone()               # caller did not zero_grad(): keep torch's += semantics
         plan = self._last
+        if plan["bwd"] is None:
+            raise RuntimeError("backward(): the last forward ran without gradient tracking (forward-only plan)")
         if (plan["B"], plan["T"]) not in self._pools or self._pools[(plan["B"], plan["T"])] is not plan["b"]:
             raise RuntimeError("backward(): the batch shape of this loss was evicted (MMFM_MAX_SHAPES) before its backward ran")
         self.b = plan["b"]

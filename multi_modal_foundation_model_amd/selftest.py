@@ -11,7 +11,7 @@ for p in (ROOT, os.path.join(ROOT, "multi_modal_foundation_model_amd", "src"), o
 
 
 def smoke():
-    from helpers import build_model, make_optimizer, tiny_config
+    from .builders import build_model, make_optimizer, tiny_config
     from oracle import mm_oracle as O
     assert torch.cuda.is_available(), "smoke() needs the MI355X"
     mc = tiny_config(n_enc=2, n_dec=2)

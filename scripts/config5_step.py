@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "multi_modal_foundation_model_amd", "src"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch
-from helpers import build_model_mods, make_optimizer, model_config
+from multi_modal_foundation_model_amd.builders import build_model_mods, make_optimizer, model_config
 import numpy as np
 sys.path.insert(0, ROOT)
 import importlib.util

@@ -4,7 +4,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "multi_modal_foundation_model_amd", "src"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
 import torch
-from helpers import build_model, load_config
+from multi_modal_foundation_model_amd.builders import build_model, load_config
 from torch.optim.lr_scheduler import OneCycleLR
 from multi_modal_foundation_model_amd.optim import make_optimizer
 from multi_modal_foundation_model_amd.synthetic import synth_batch
