@@ -318,9 +318,13 @@ int mmfm_mlp_bwd(const mmfm_mlp_desc* d, mmfm_stream stream);
  *   Gdb = [ G[N][K] | db[N] ],  G = dY^T x_hat,  db = colsum dY   (one mmfm_gemm + mmfm_reduce_slabs)
  *   dW[n][k] = gamma[k] * G[n][k] + db[n] * beta[k];   dbias = db;
  *   dgamma[k] (+)= sum_n W[n][k] * G[n][k];   dbeta[k] (+)= sum_n W[n][k] * db[n]      (accumulate_ln selects +=)
- * No per-row reduction is needed for the LayerNorm parameters.  Deterministic. */
+ * No per-row reduction is needed for the LayerNorm parameters.  Deterministic.
+ * workspace: mmfm_ln_linear_grad_workspace(K) bytes, ZEROED once before its first use (partial rows + arrival tickets that
+ * the kernel re-arms itself); one workspace per concurrently running launch. */
+int64_t mmfm_ln_linear_grad_workspace(int K);
 int mmfm_ln_linear_grad(const float* Gdb, const float* W, const float* gamma, const float* beta, int N, int K,
-                        float* dW, float* dbias, float* dgamma, float* dbeta, int accumulate_ln, mmfm_stream stream);
+                        float* dW, float* dbias, float* dgamma, float* dbeta, int accumulate_ln,
+                        void* workspace, int64_t workspace_bytes, mmfm_stream stream);
 
 #ifdef __cplusplus
 }

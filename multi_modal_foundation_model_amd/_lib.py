@@ -104,7 +104,8 @@ _PROTOS = {
     "mmfm_rowgemm": (C.c_int, [C.POINTER(RowGemmDesc), _vp]),
     "mmfm_mlp_fwd": (C.c_int, [C.POINTER(MlpDesc), _vp]),
     "mmfm_mlp_bwd": (C.c_int, [C.POINTER(MlpDesc), _vp]),
-    "mmfm_ln_linear_grad": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp]),
+    "mmfm_ln_linear_grad_workspace": (C.c_int64, [_i]),
+    "mmfm_ln_linear_grad": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _vp, _i64, _vp]),
     "mmfm_r2_series": (C.c_int, [_vp, C.POINTER(_i64), _vp, C.POINTER(_i64), _i, _i, _i, _vp, _vp]),
     "mmfm_bits_per_spike_workspace": (C.c_int64, [_i64, _i]),
     "mmfm_bits_per_spike": (C.c_int, [_vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),

@@ -23,17 +23,23 @@ constexpr int NT = 256, NW = 4;
 
 __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + NW * STG_BYTES + 768 * 4];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, m = lane & 31, h = lane >> 5;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
     const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
     const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
     if (my_passes == 0) return;
     const uint16_t* Wup = reinterpret_cast<const uint16_t*>(d.w_up);
     const uint16_t* Wdn = reinterpret_cast<const uint16_t*>(d.w_down);
     const int rot = d.rotate ? (int)(blockIdx.x & 15) : 0;
+    // software pipeline: the up-projection of tile k+1 is multiplied WHILE the GELU of tile k runs on the vector unit (one wave
+    // per SIMD: the only MFMA / VALU overlap there is, is inside the wave's own instruction stream).  Chunk order per pass:
+    //   up(0) | up(1) down(0) | up(2) down(1) | ... | up(15) down(14) | down(15)
     auto src = [=](int g) {
-        const int idx = g & 31, tt = ((idx >> 1) + rot) & 15;
+        const int idx = g & 31;
+        const bool is_up = idx == 0 || (idx < 31 && (idx & 1));
+        const int k = idx == 0 ? 0 : (idx == 31 ? 15 : (is_up ? (idx + 1) >> 1 : (idx >> 1) - 1));
+        const int tt = (k + rot) & 15;
         WChunk c;
-        if (idx & 1) { c.base = Wdn + 32 * tt; c.ld = 512; c.kind = 2; }
+        if (!is_up) { c.base = Wdn + 32 * tt; c.ld = 512; c.kind = 2; }
         else { c.base = Wup + (size_t)(32 * tt) * 256; c.ld = 256; c.kind = 0; }
         return c;
     };
@@ -58,22 +64,48 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
         f32x16 Y8[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) Y8[i] = zero16();
-        for (int ti = 0; ti < 16; ++ti) {
-            const int tt = (ti + rot) & 15;
-            const char* slot;
-            RING_STEP(src, slot);
-            f32x16 U = mma16(slot, x, zero16(), m, h);
+        const char* slot;
+        RING_STEP(src, slot);
+        f32x16 U = mma16<4>(slot, x, zero16(), m, h);                  // up(0)
+        for (int k = 0; k < 16; ++k) {
+            const int tt = (k + rot) & 15;
             add_vec(U, lb_up, tt, h);
+            f32x16 Un = zero16();
+            if (k < 15) {                                               // up(k+1) interleaved with gelu(k), element by element
+                RING_STEP(src, slot);
+                opnd wf[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) U[i] = gelu_fast(U[i]);
+                for (int part = 0; part < 4; ++part) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) wf[s] = wfragA(slot, 4 * part + s, m, h);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        Un = mfma(wf[s], x[4 * part + s], Un);
+                        U[4 * part + s] = gelu_fast(U[4 * part + s]);
+                    }
+                }
+                // hipcc clusters the 16 MFMAs and runs the GELU behind them; pin the interleave: per MFMA one LDS read, the
+                // ~18 vector + 2 transcendental instructions of one GELU (cdna_hip_programming.md T19)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) U[i] = gelu_fast(U[i]);
+            }
             opnd g0, g1;
             acc_to_opnd(U, g0, g1);
-            RING_STEP(src, slot);
+            RING_STEP(src, slot);                                       // down(k)
 #pragma unroll
             for (int t2 = 0; t2 < 8; ++t2) {
                 Y8[t2] = mfma(wfragB(slot, t2, 0, m, h), g0, Y8[t2]);
                 Y8[t2] = mfma(wfragB(slot, t2, 1, m, h), g1, Y8[t2]);
             }
+            U = Un;
         }
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) {
@@ -101,7 +133,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
 
 __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + 3 * NW * STG_BYTES + 512 * 4];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, m = lane & 31, h = lane >> 5;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
     const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
     const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
     if (my_passes == 0) return;
@@ -217,18 +249,290 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
     }
 }
 
-// dW = gamma * G + db x beta; dgamma = colsum(W * G); dbeta = W^T db.  One block per 32 columns k, 8 row groups.
+// ------------------------------------------------------------------------------------------------ wave-pair versions
+// The one-wave-per-row-tile kernels above need ~450 registers (one wave per SIMD, operands bouncing through the accumulator
+// file, GELU serialised with the MFMAs).  Here waves w and w+4 own the SAME 32 rows and split the work, so each fits 256
+// registers and every SIMD runs two waves (VALU of one beside MFMAs of the other, vector issue at the two-wave rate):
+//   forward : both hold x_hat; wave A takes intermediate tiles 2u, wave B 2u+1 (up-projection + GELU), they swap the bf16
+//             operands of g through LDS, and each accumulates HALF of the 256 output columns over all of g.
+//   backward: A holds x_hat and recomputes u (both tiles of a pair), B holds t1 = dropout'(dy) and computes dg; A hands
+//             gelu'(u) to B, B forms du and hands its operands back; each accumulates half of d(x_hat); the LayerNorm
+//             backward sums its row statistics across the pair.
+// Chunks are 32 KB (two 16 KB sub-blocks, one per role or one per intermediate tile of the pair).
+constexpr int NT8 = 512;
+
+__global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
+    constexpr int NPAIR = 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * CHUNK2 + 8 * STG_BYTES + NPAIR * 2 * 2048 + 768 * 4];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
+    const int role = wave >> 2, pw = wave & 3;
+    const int64_t npass = (d.R + 32 * NPAIR - 1) / (32 * NPAIR);
+    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
+    if (my_passes == 0) return;
+    const uint16_t* Wup = reinterpret_cast<const uint16_t*>(d.w_up);
+    const uint16_t* Wdn = reinterpret_cast<const uint16_t*>(d.w_down);
+    const int rot = d.rotate ? (int)(blockIdx.x & 7) : 0;
+    auto src = [=](int g) {
+        const int idx = g & 15, u = ((idx >> 1) + rot) & 7;
+        WChunk2 c;
+        if (idx & 1) {
+            c.s[0].base = Wdn + 64 * u; c.s[0].ld = 512; c.s[0].kind = 2;
+            c.s[1].base = Wdn + 64 * u + 32; c.s[1].ld = 512; c.s[1].kind = 2;
+        } else {
+            c.s[0].base = Wup + (size_t)(64 * u) * 256; c.s[0].ld = 256; c.s[0].kind = 0;
+            c.s[1].base = Wup + (size_t)(64 * u + 32) * 256; c.s[1].ld = 256; c.s[1].kind = 0;
+        }
+        return c;
+    };
+    char* stg = smem + 2 * CHUNK2 + wave * STG_BYTES;
+    char* exch = smem + 2 * CHUNK2 + 8 * STG_BYTES + pw * 4096;            // [role][2 operands][64 lanes][16 B]
+    float* lb_up = reinterpret_cast<float*>(smem + 2 * CHUNK2 + 8 * STG_BYTES + NPAIR * 4096);
+    float* lb_dn = lb_up + 512;
+    stage_vec(lb_up, d.b_up, 512, t, NT8);
+    stage_vec(lb_dn, d.b_down, 256, t, NT8);
+    const Drop dr = drop_init(d.drop);
+    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2);
+    const GBuf XH = gbuf(role == 0 ? d.xhat : nullptr, d.R * 512), RS = gbuf(role == 0 ? d.rstd : nullptr, d.R * 4);
+    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2;
+    RING2_DECL(NT8);
+    RING2_START(smem, my_passes * 16, src);
+    for (int pi = 0; pi < my_passes; ++pi) {
+        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NPAIR + pw) * 32);
+        const uint32_t row = wrow0 + m;
+        opnd x[16];
+        load_rows_lines<4>(stg, x, X, wrow0, ldxb, lane, m, h);
+        const float rs = ln_rows(x, d.eps);
+        store_rows_lines<4, false>(stg, XH, wrow0, 512u, lane, m, h, x);       // role 1: zero-sized buffer, dropped
+        st4f(RS, h == 0 ? row * 4u : 0xfffffff0u, rs);
+        f32x16 Yh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Yh[i] = zero16();
+        for (int ui = 0; ui < 8; ++ui) {
+            const int u = (ui + rot) & 7;
+            const char* slot;
+            RING2_STEP(src, slot);
+            f32x16 U = mma16<4>(slot + role * CHUNK, x, zero16(), m, h);
+            add_vec(U, lb_up, 2 * u + role, h);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) U[i] = gelu_fast(U[i]);
+            opnd g0, g1;
+            acc_to_opnd(U, g0, g1);
+            *reinterpret_cast<uint4*>(exch + role * 2048 + lane * 16) = as_u4(g0);
+            *reinterpret_cast<uint4*>(exch + role * 2048 + 1024 + lane * 16) = as_u4(g1);
+            RING2_STEP(src, slot);                                              // its barrier publishes the pair's operands
+            const opnd p0 = as_opnd(*reinterpret_cast<const uint4*>(exch + (role ^ 1) * 2048 + lane * 16));
+            const opnd p1 = as_opnd(*reinterpret_cast<const uint4*>(exch + (role ^ 1) * 2048 + 1024 + lane * 16));
+            const opnd e0 = role == 0 ? g0 : p0, e1 = role == 0 ? g1 : p1;      // tile 2u   (even)
+            const opnd o0 = role == 0 ? p0 : g0, o1 = role == 0 ? p1 : g1;      // tile 2u+1 (odd)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t2 = 4 * role + j;
+                Yh[j] = mfma(wfragB(slot, t2, 0, m, h), e0, Yh[j]);
+                Yh[j] = mfma(wfragB(slot, t2, 1, m, h), e1, Yh[j]);
+                Yh[j] = mfma(wfragB(slot + CHUNK, t2, 0, m, h), o0, Yh[j]);
+                Yh[j] = mfma(wfragB(slot + CHUNK, t2, 1, m, h), o1, Yh[j]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int lp = 2 * role + q;                                        // line pair = output tiles 2*lp, 2*lp+1
+            const Lines xl = fetch_lines(X, wrow0, ldxb, 128u * lp, lane);
+            stage_lines(stg, xl, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int t2 = 2 * lp + j;
+                add_vec(Yh[2 * q + j], lb_dn, t2, h);
+                if (dr.on()) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        Yh[2 * q + j][i] = dr.keep((uint64_t)row * 256u + (uint64_t)feat(t2, i, h)) ? Yh[2 * q + j][i] * dr.scale : 0.f;
+                }
+                const f32x16 r = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Yh[2 * q + j][i] += r[i];
+            }
+            stage_tile(stg, 0, m, h, Yh[2 * q]);
+            stage_tile(stg, 1, m, h, Yh[2 * q + 1]);
+            flush_lines<false>(stg, Y, wrow0, ldyb, 128u * lp, lane);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT8) void mlp_bwd8_kernel(const mmfm_mlp_desc d) {
+    constexpr int NPAIR = 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * CHUNK2 + 8 * STG_BYTES + NPAIR * 4096 + 8 * 32 * 8 + 512 * 4];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
+    const int role = wave >> 2, pw = wave & 3;
+    const int64_t npass = (d.R + 32 * NPAIR - 1) / (32 * NPAIR);
+    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
+    if (my_passes == 0) return;
+    const uint16_t* Wup = reinterpret_cast<const uint16_t*>(d.w_up);
+    const uint16_t* WdnT = reinterpret_cast<const uint16_t*>(d.w_down_t);
+    const uint16_t* WupT = reinterpret_cast<const uint16_t*>(d.w_up_t);
+    const int rot = d.rotate ? (int)(blockIdx.x & 7) : 0;
+    auto src = [=](int g) {                              // per pair of intermediate tiles (2u, 2u+1): three chunks
+        const int idx = g % 24, ui = idx / 3, k = idx - 3 * ui, u = (ui + rot) & 7;
+        WChunk2 c;
+        if (k < 2) {                                     // tile 2u + k: [Wp_up rows (recompute, role A) | W_down^T rows (dg, role B)]
+            c.s[0].base = Wup + (size_t)(32 * (2 * u + k)) * 256; c.s[0].ld = 256; c.s[0].kind = 0;
+            c.s[1].base = WdnT + (size_t)(32 * (2 * u + k)) * 256; c.s[1].ld = 256; c.s[1].kind = 0;
+        } else {                                         // Wp_up^T columns of the two tiles (d x_hat += du . Wp_up)
+            c.s[0].base = WupT + 64 * u; c.s[0].ld = 512; c.s[0].kind = 2;
+            c.s[1].base = WupT + 64 * u + 32; c.s[1].ld = 512; c.s[1].kind = 2;
+        }
+        return c;
+    };
+    char* stg = smem + 2 * CHUNK2 + wave * STG_BYTES;
+    char* exch = smem + 2 * CHUNK2 + 8 * STG_BYTES + pw * 4096;            // 4 x [64 lanes][16 B]: gelu'(u) (A->B), then du operands (B->A)
+    float2* sx = reinterpret_cast<float2*>(smem + 2 * CHUNK2 + 8 * STG_BYTES + NPAIR * 4096);      // [wave][32 rows]
+    float* lb_up = reinterpret_cast<float*>(smem + 2 * CHUNK2 + 8 * STG_BYTES + NPAIR * 4096 + 8 * 32 * 8);
+    stage_vec(lb_up, d.b_up, 512, t, NT8);
+    const Drop dr = drop_init(d.drop);
+    const GBuf XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4), DY = gbuf(d.dy, d.R * d.lddy * 2);
+    const GBuf T1 = gbuf(role == 1 ? d.t1 : nullptr, d.R * 512);
+    const GBuf GD = gbuf(role == 0 ? d.g : d.du, d.R * 1024), DX = gbuf(d.dx, d.R * d.lddx * 2);
+    const uint32_t lddyb = d.lddy * 2, lddxb = d.lddx * 2;
+    RING2_DECL(NT8);
+    RING2_START(smem, my_passes * 24, src);
+    for (int pi = 0; pi < my_passes; ++pi) {
+        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NPAIR + pw) * 32);
+        const uint32_t row = wrow0 + m;
+        opnd x[16];                                      // role A: x_hat;  role B: t1 = dropout'(dy)
+        if (role == 0) load_rows_lines<4>(stg, x, XH, wrow0, 512u, lane, m, h);
+        else {
+            load_rows_lines<4>(stg, x, DY, wrow0, lddyb, lane, m, h);
+            if (dr.on()) {                               // counter row*256 + k, k = 16s + 8h + j
+#pragma unroll
+                for (int s = 0; s < 16; ++s) {
+                    float f[8]; unpack8f(x[s], f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        f[j] = dr.keep((uint64_t)row * 256u + (uint64_t)(16 * s + 8 * h + j)) ? f[j] * dr.scale : 0.f;
+                    x[s] = pack8o(f);
+                }
+            }
+            store_rows_lines<4, true>(stg, T1, wrow0, 512u, lane, m, h, x);
+        }
+        f32x16 DH[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) DH[i] = zero16();
+        for (int ui = 0; ui < 8; ++ui) {
+            const int u = (ui + rot) & 7;
+            const char* slot;
+            f32x16 A2[2];                                // role A: u of tiles 2u, 2u+1;  role B: dg of the same tiles
+            RING2_STEP(src, slot);
+            A2[0] = mma16<4>(slot + role * CHUNK, x, zero16(), m, h);
+            RING2_STEP(src, slot);
+            A2[1] = mma16<4>(slot + role * CHUNK, x, zero16(), m, h);
+            if (role == 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    add_vec(A2[j], lb_up, 2 * u + j, h);
+                    uint32_t gp[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) gp[i] = pack2(gelu_grad_fast(A2[j][2 * i]), gelu_grad_fast(A2[j][2 * i + 1]));
+                    *reinterpret_cast<uint4*>(exch + (2 * j) * 1024 + lane * 16) = make_uint4(gp[0], gp[1], gp[2], gp[3]);
+                    *reinterpret_cast<uint4*>(exch + (2 * j + 1) * 1024 + lane * 16) = make_uint4(gp[4], gp[5], gp[6], gp[7]);
+                }
+            }
+            __syncthreads();                             // gelu'(u) of the pair visible to B
+            opnd du[4];
+            if (role == 1) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const uint4 a = *reinterpret_cast<const uint4*>(exch + (2 * j) * 1024 + lane * 16);
+                    const uint4 b = *reinterpret_cast<const uint4*>(exch + (2 * j + 1) * 1024 + lane * 16);
+                    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { A2[j][2 * i] *= lo_f(w[i]); A2[j][2 * i + 1] *= hi_f(w[i]); }
+                    acc_to_opnd(A2[j], du[2 * j], du[2 * j + 1]);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) A2[j][i] = gelu_fast(A2[j][i]);
+            }
+            // both roles: their tile pair (A: g, B: du) leaves as whole lines of the [R][512] tensor
+            stage_tile(stg, 0, m, h, A2[0]);
+            stage_tile(stg, 1, m, h, A2[1]);
+            flush_lines<true>(stg, GD, wrow0, 1024u, 128u * u, lane);
+            __syncthreads();                             // every B has read gelu'(u): the exchange area is free again
+            if (role == 1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(exch + i * 1024 + lane * 16) = as_u4(du[i]);
+            }
+            RING2_STEP(src, slot);                       // its barrier publishes du's operands
+            if (role == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) du[i] = as_opnd(*reinterpret_cast<const uint4*>(exch + i * 1024 + lane * 16));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int t2 = 4 * role + j;
+                DH[j] = mfma(wfragB(slot, t2, 0, m, h), du[0], DH[j]);
+                DH[j] = mfma(wfragB(slot, t2, 1, m, h), du[1], DH[j]);
+                DH[j] = mfma(wfragB(slot + CHUNK, t2, 0, m, h), du[2], DH[j]);
+                DH[j] = mfma(wfragB(slot + CHUNK, t2, 1, m, h), du[3], DH[j]);
+            }
+        }
+        // LayerNorm backward: this wave's half of the columns (line pairs 2*role, 2*role+1), statistics summed over the pair
+        f32x16 xt[4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const Lines xl = fetch_lines(XH, wrow0, 512u, 128u * (2 * role + q), lane);
+            stage_lines(stg, xl, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                xt[2 * q + j] = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s1 += DH[2 * q + j][i]; s2 = fmaf(DH[2 * q + j][i], xt[2 * q + j][i], s2); }
+            }
+        }
+        s1 = xhalf(s1); s2 = xhalf(s2);
+        if (h == 0) sx[wave * 32 + m] = make_float2(s1, s2);
+        __syncthreads();
+        const float2 o2 = sx[(wave ^ 4) * 32 + m];
+        s1 = (s1 + o2.x) * (1.f / 256.f);
+        s2 = (s2 + o2.y) * (1.f / 256.f);
+        const float rs = ld4f(RS, row * 4u);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const Lines rl = fetch_lines(DY, wrow0, lddyb, 128u * (2 * role + q), lane);
+            stage_lines(stg, rl, lane);
+            f32x16 o[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 r = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[j][i] = r[i] + rs * (DH[2 * q + j][i] - s1 - xt[2 * q + j][i] * s2);
+            }
+            stage_tile(stg, 0, m, h, o[0]);
+            stage_tile(stg, 1, m, h, o[1]);
+            flush_lines<false>(stg, DX, wrow0, lddxb, 128u * (2 * role + q), lane);
+        }
+    }
+}
+
+// dW = gamma * G + db x beta; dgamma = colsum(W * G); dbeta = W^T db.  Grid (K/32 column groups) x (NSPLIT row groups): every
+// block writes its dW rows and a partial (dgamma, dbeta) row; the LAST block of a column group (agent-scope ticket) sums the
+// NSPLIT partials in fixed order -> deterministic, one launch.
+constexpr int LG_SPLIT = 16;
 __global__ __launch_bounds__(256) void ln_linear_grad_kernel(const float* __restrict__ Gdb, const float* __restrict__ W,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, int N, int K,
                                                             float* __restrict__ dW, float* __restrict__ dbias, float* __restrict__ dgamma,
-                                                            float* __restrict__ dbeta, int accumulate) {
+                                                            float* __restrict__ dbeta, int accumulate, float* __restrict__ part,
+                                                            unsigned int* __restrict__ ticket) {
     __shared__ float red[2][8][32];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, k = blockIdx.x * 32 + tx;
+    __shared__ int is_last;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5, k = blockIdx.x * 32 + tx, sp = blockIdx.y;
     const float* db = Gdb + (size_t)N * K;
+    const int rows_per = (N + LG_SPLIT - 1) / LG_SPLIT, n0 = sp * rows_per, n1 = min(N, n0 + rows_per);
     float ag = 0.f, ab = 0.f;
     if (k < K) {
         const float g = gamma[k], b = beta[k];
-        for (int n = ty; n < N; n += 8) {
+        for (int n = n0 + ty; n < n1; n += 8) {
             const float Gv = Gdb[(size_t)n * K + k], w = W[(size_t)n * K + k], dbn = db[n];
             dW[(size_t)n * K + k] = fmaf(g, Gv, dbn * b);
             ag = fmaf(w, Gv, ag);
@@ -241,14 +545,35 @@ __global__ __launch_bounds__(256) void ln_linear_grad_kernel(const float* __rest
         float sg = 0.f, sb = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) { sg += red[0][i][tx]; sb += red[1][i][tx]; }
+        part[((size_t)sp * 2 + 0) * K + k] = sg;
+        part[((size_t)sp * 2 + 1) * K + k] = sb;
+    }
+    if (blockIdx.x == 0) for (int n = n0 + threadIdx.x; n < n1; n += 256) dbias[n] = db[n];
+    // publish the partial row, take a ticket; the last arriver of this column group reduces (cdna_hip_programming.md Guideline 16)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned int prev = __hip_atomic_fetch_add(&ticket[blockIdx.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = (prev == (unsigned int)(LG_SPLIT - 1));
+        if (is_last) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); ticket[blockIdx.x] = 0u; }      // re-armed for the next launch
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (is_last && ty == 0 && k < K) {
+        float sg = 0.f, sb = 0.f;
+        for (int i = 0; i < LG_SPLIT; ++i) {
+            sg += __builtin_nontemporal_load(&part[((size_t)i * 2 + 0) * K + k]);
+            sb += __builtin_nontemporal_load(&part[((size_t)i * 2 + 1) * K + k]);
+        }
         dgamma[k] = accumulate ? dgamma[k] + sg : sg;
         dbeta[k] = accumulate ? dbeta[k] + sb : sb;
     }
-    if (blockIdx.x == 0) for (int n = threadIdx.x; n < N; n += 256) dbias[n] = db[n];
 }
 
-int grid_for(int64_t R, int per_cu) {
-    const int64_t npass = (R + 32 * NW - 1) / (32 * NW);
+int grid_for(int64_t R, int per_cu, int nw = NW) {
+    const int64_t npass = (R + 32 * nw - 1) / (32 * nw);
     return (int)std::max<int64_t>(1, std::min<int64_t>(npass, 256 * per_cu));
 }
 
@@ -271,7 +596,9 @@ extern "C" int mmfm_mlp_fwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     const mmfm_mlp_desc d = *dp;
     if (int rc = check(d, false)) return rc;
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
-    hipLaunchKernelGGL(mlp_fwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), 0, (hipStream_t)stream, d);
+    static const int v1 = [] { const char* e = getenv("MMFM_MLP_V1"); return e ? atoi(e) : 0; }();
+    if (!v1) hipLaunchKernelGGL(mlp_fwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), 0, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(mlp_fwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), 0, (hipStream_t)stream, d);
     MMFM_LAUNCH_CHECK("mmfm_mlp_fwd");
     return 0;
 }
@@ -280,16 +607,24 @@ extern "C" int mmfm_mlp_bwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     const mmfm_mlp_desc d = *dp;
     if (int rc = check(d, true)) return rc;
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
-    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), 0, (hipStream_t)stream, d);
+    static const int v1 = [] { const char* e = getenv("MMFM_MLP_V1"); return e ? atoi(e) : 0; }();
+    if (!v1) hipLaunchKernelGGL(mlp_bwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), 0, (hipStream_t)stream, d);
+    else hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), 0, (hipStream_t)stream, d);
     MMFM_LAUNCH_CHECK("mmfm_mlp_bwd");
     return 0;
 }
 
+extern "C" int64_t mmfm_ln_linear_grad_workspace(int K) { return ((int64_t)LG_SPLIT * 2 * K + cdiv(K, 32) + 64) * 4; }
+
 extern "C" int mmfm_ln_linear_grad(const float* Gdb, const float* W, const float* gamma, const float* beta, int N, int K, float* dW,
-                                   float* dbias, float* dgamma, float* dbeta, int accumulate_ln, mmfm_stream stream) {
+                                   float* dbias, float* dgamma, float* dbeta, int accumulate_ln, void* workspace, int64_t workspace_bytes,
+                                   mmfm_stream stream) {
     MMFM_REQUIRE(Gdb && W && gamma && beta && dW && dbias && dgamma && dbeta && N > 0 && K > 0, "mmfm_ln_linear_grad: null argument");
-    hipLaunchKernelGGL(ln_linear_grad_kernel, dim3(cdiv(K, 32)), dim3(256), 0, (hipStream_t)stream, Gdb, W, gamma, beta, N, K, dW, dbias, dgamma,
-                       dbeta, accumulate_ln);
+    MMFM_REQUIRE(workspace && workspace_bytes >= mmfm_ln_linear_grad_workspace(K), "mmfm_ln_linear_grad: workspace too small (must be ZEROED once before first use)");
+    float* part = reinterpret_cast<float*>(workspace);
+    unsigned int* ticket = reinterpret_cast<unsigned int*>(part + (size_t)LG_SPLIT * 2 * K);
+    hipLaunchKernelGGL(ln_linear_grad_kernel, dim3(cdiv(K, 32), LG_SPLIT), dim3(256), 0, (hipStream_t)stream, Gdb, W, gamma, beta, N, K, dW, dbias, dgamma,
+                       dbeta, accumulate_ln, part, ticket);
     MMFM_LAUNCH_CHECK("mmfm_ln_linear_grad");
     return 0;
 }

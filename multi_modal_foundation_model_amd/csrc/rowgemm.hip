@@ -23,10 +23,10 @@ constexpr int BIAS_MAX = 1024;                      // floats of bias kept in LD
 // NWV waves per workgroup (8 = two per SIMD wherever the registers allow: the barrier / LDS-write overhead of a chunk is
 // paid once per 256 rows instead of 128 and a SIMD's MFMA pipe is fed by two waves), 32 rows each
 template <int KP, bool LN, bool NTS, int NWV>
-__global__ __launch_bounds__(NWV * 64) void rowgemm_kernel(const mmfm_rowgemm_desc d) {
+__global__ __launch_bounds__(NWV * 64, (KP == 1 ? 2 : 1)) void rowgemm_kernel(const mmfm_rowgemm_desc d) {
     constexpr int NT = NWV * 64, NW = NWV;
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + NW * STG_BYTES + BIAS_MAX * 4];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, m = lane & 31, h = lane >> 5;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
     const int npair = d.N >> 6, cpp = 2 * npair * KP;                   // N % 64 == 0
     const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
     const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
@@ -93,13 +93,180 @@ __global__ __launch_bounds__(NWV * 64) void rowgemm_kernel(const mmfm_rowgemm_de
     }
 }
 
+// ------------------------------------------------------------------------------------------------ K = 256, eight waves, skewed
+// The K = 256 products (ln1+qkv, query, key/value, context projection, out_proj and its dX) as ONE 512-thread workgroup per
+// CU: 32 KB chunks (a pair of 32-row weight tiles = 32 MFMAs per wave per barrier) and the two wave groups SKEWED by half a
+// step - waves 0-3 multiply chunk c and then run its epilogue, waves 4-7 run the epilogue of chunk c-1 and then multiply
+// chunk c - so that on every SIMD one wave's MFMAs run beside its partner's epilogue (VALU + LDS staging + stores) instead
+// of both waves idling the matrix pipe together (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
+template <bool LN, bool NTS, bool HAS_RES>
+__global__ __launch_bounds__(512) void rowgemm8_kernel(const mmfm_rowgemm_desc d) {
+    constexpr int NT = 512, NW = 8;
+    __shared__ __attribute__((aligned(16))) char smem[2 * CHUNK2 + NW * STG_BYTES + BIAS_MAX * 4];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
+    const int npair = d.N >> 6;
+    const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
+    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
+    if (my_passes == 0) return;
+    const uint16_t* W = reinterpret_cast<const uint16_t*>(d.w);
+    const int ldw = d.ldw;
+    const int rot = d.rotate ? (int)(blockIdx.x % npair) : 0;
+    auto src = [=](int g) {
+        int pr = g % npair + rot; pr = pr >= npair ? pr - npair : pr;
+        WChunk2 c;
+        c.s[0].base = W + (size_t)(64 * pr) * ldw; c.s[0].ld = ldw; c.s[0].kind = 0;
+        c.s[1].base = W + (size_t)(64 * pr + 32) * ldw; c.s[1].ld = ldw; c.s[1].kind = 0;
+        return c;
+    };
+    char* stg = smem + 2 * CHUNK2 + wave * STG_BYTES;
+    float* lbias = reinterpret_cast<float*>(smem + 2 * CHUNK2 + NW * STG_BYTES);
+    stage_vec(lbias, d.bias, d.N, t, NT);
+    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), RES = gbuf(d.residual, d.R * d.ldr * 2);
+    const GBuf XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4);
+    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2, ldrb = d.ldr * 2;
+    const bool late = wave >= 4;                         // wave-uniform: this group's epilogue trails its MFMAs by one step
+    RING2_DECL(NT);
+    RING2_START(smem, my_passes * npair, src);
+    auto epilogue = [&](f32x16 (&acc)[2], int pr, uint32_t wrow0, const Lines& res) {
+        add_vec(acc[0], lbias, 2 * pr, h);
+        add_vec(acc[1], lbias, 2 * pr + 1, h);
+        if constexpr (HAS_RES) {
+            stage_lines(stg, res, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 r = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[j][i] += r[i];
+            }
+        }
+        stage_tile(stg, 0, m, h, acc[0]);
+        stage_tile(stg, 1, m, h, acc[1]);
+        flush_lines<NTS>(stg, Y, wrow0, ldyb, 128u * pr, lane);
+    };
+    for (int pi = 0; pi < my_passes; ++pi) {
+        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
+        const bool live = wrow0 < (uint32_t)d.R;          // a wave without rows only keeps the ring's barriers
+        opnd x[16];
+        if (live) load_rows_lines<4>(stg, x, X, wrow0, ldxb, lane, m, h);
+        if constexpr (LN) if (live) {
+            const float rs = ln_rows(x, d.eps);
+            store_rows_lines<4, false>(stg, XH, wrow0, 512u, lane, m, h, x);
+            st4f(RS, h == 0 ? (wrow0 + m) * 4u : 0xfffffff0u, rs);
+        }
+        f32x16 acc[2];                                    // late group: holds the previous step's tile pair until its epilogue
+        int prp = 0;
+        for (int tp = 0; tp < npair; ++tp) {
+            int pr = tp + rot; pr = pr >= npair ? pr - npair : pr;
+            RING2_SYNC_WRITE(src);
+            Lines res;
+            if constexpr (HAS_RES) res = fetch_lines(RES, wrow0, ldrb, 128u * (late ? prp : pr), lane);
+            const char* slot;
+            RING2_FETCH(src, slot);
+            if (!live) continue;
+            if (late && tp > 0) epilogue(acc, prp, wrow0, res);
+            acc[0] = mma16<4>(slot, x, zero16(), m, h);
+            acc[1] = mma16<4>(slot + CHUNK, x, zero16(), m, h);
+            if (!late) epilogue(acc, pr, wrow0, res);
+            prp = pr;
+        }
+        if (late && live) {
+            Lines res;
+            if constexpr (HAS_RES) res = fetch_lines(RES, wrow0, ldrb, 128u * prp, lane);
+            epilogue(acc, prp, wrow0, res);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ K = 256, stager wave + 7 compute waves
+template <bool LN, bool NTS, bool HAS_RES>
+__global__ __launch_bounds__(512) void rowgemm7_kernel(const mmfm_rowgemm_desc d) {
+    constexpr int NC = 7;                                // compute waves (32 rows each); wave 7 streams the weights
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + NC * STG_BYTES + BIAS_MAX * 4];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
+    const int ntile = d.N >> 5, npair = d.N >> 6;
+    const int64_t npass = (d.R + 32 * NC - 1) / (32 * NC);
+    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
+    if (my_passes == 0) return;
+    const uint16_t* W = reinterpret_cast<const uint16_t*>(d.w);
+    const int ldw = d.ldw;
+    const int rot = d.rotate ? (int)(blockIdx.x % npair) : 0;
+    auto src = [=](int g) {
+        const int ti = g % ntile;
+        int pr = (ti >> 1) + rot; pr = pr >= npair ? pr - npair : pr;
+        WChunk c;
+        c.base = W + (size_t)(32 * (2 * pr + (ti & 1))) * ldw; c.ld = ldw; c.kind = 0;
+        return c;
+    };
+    float* lbias = reinterpret_cast<float*>(smem + LDS_BYTES + NC * STG_BYTES);
+    stage_vec(lbias, d.bias, d.N, t, 512);              // visible after the first step's barrier
+    if (wave == NC) { weight_stager(smem, my_passes * ntile, src, lane); return; }
+    char* ws_smem = smem;
+    char* stg = smem + LDS_BYTES + wave * STG_BYTES;
+    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), RES = gbuf(d.residual, d.R * d.ldr * 2);
+    const GBuf XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4);
+    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2, ldrb = d.ldr * 2;
+    int g = 0;
+    uint32_t wrow0 = (uint32_t)(((int64_t)blockIdx.x * NC + wave) * 32);
+    Lines L[4];                                          // the NEXT pass's rows, in flight during this pass's products
+#pragma unroll
+    for (int q = 0; q < 4; ++q) L[q] = fetch_lines(X, wrow0, ldxb, 128u * q, lane);
+    for (int pi = 0; pi < my_passes; ++pi) {
+        const bool live = wrow0 < (uint32_t)d.R;
+        const uint32_t nrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)(pi + 1) * gridDim.x) * NC + wave) * 32);
+        opnd x[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            stage_lines(stg, L[q], lane);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) x[4 * q + s4] = unstage_opnd(stg, s4, m, h);
+            L[q] = fetch_lines(X, nrow0, ldxb, 128u * q, lane);          // beyond the tensor: reads as zero, costs nothing
+        }
+        if constexpr (LN) {
+            const float rs = ln_rows(x, d.eps);
+            store_rows_lines<4, false>(stg, XH, wrow0, 512u, lane, m, h, x);
+            st4f(RS, h == 0 ? (wrow0 + m) * 4u : 0xfffffff0u, rs);
+        }
+        Lines res;
+        if constexpr (HAS_RES) { int pr0 = rot; res = fetch_lines(RES, wrow0, ldrb, 128u * pr0, lane); }
+        for (int tp = 0; tp < npair; ++tp) {
+            int pr = tp + rot; pr = pr >= npair ? pr - npair : pr;
+            int prn = pr + 1; prn = prn >= npair ? prn - npair : prn;
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const char* slot;
+                WS_STEP(slot, g);
+                acc[j] = zero16();
+                if (live) acc[j] = mma16<4>(slot, x, acc[j], m, h);
+            }
+            if (!live) continue;
+            add_vec(acc[0], lbias, 2 * pr, h);
+            add_vec(acc[1], lbias, 2 * pr + 1, h);
+            if constexpr (HAS_RES) {
+                stage_lines(stg, res, lane);
+                if (tp + 1 < npair) res = fetch_lines(RES, wrow0, ldrb, 128u * prn, lane);    // one pair ahead
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x16 r = unstage_tile(stg, j, m, h);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[j][i] += r[i];
+                }
+            }
+            stage_tile(stg, 0, m, h, acc[0]);
+            stage_tile(stg, 1, m, h, acc[1]);
+            flush_lines<NTS>(stg, Y, wrow0, ldyb, 128u * pr, lane);
+        }
+        wrow0 = nrow0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ dX + LayerNorm backward
 // v = x . W^T (N = 256: the gradient wrt x_hat of the LayerNorm that fed the forward linear; W = prepared W'^T);
 // y = dres + rstd * (v - mean(v) - x_hat * mean(v * x_hat))
 template <int KP>
 __global__ __launch_bounds__(NT) void rowgemm_lnbwd_kernel(const mmfm_rowgemm_desc d) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + NW * STG_BYTES];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, m = lane & 31, h = lane >> 5;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
     constexpr int cpp = 8 * KP;
     const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
     const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
@@ -177,6 +344,103 @@ __global__ __launch_bounds__(NT) void rowgemm_lnbwd_kernel(const mmfm_rowgemm_de
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dX + LayerNorm backward, wave pairs
+// Eight waves; waves w and w+4 own the SAME 32 rows and split the 256 output columns (tiles 0-3 / 4-7): 64 accumulator
+// registers each instead of 128, the K = 256*KP input streamed one 256-wide piece at a time (64 registers + the next piece in
+// flight) -> two waves per SIMD fit where the one-wave version needed 512 registers and spent its time copying operands out
+// of the accumulator file.  A 32 KB chunk = the two groups' weight tiles of one (piece, tile) step; the row statistics of the
+// LayerNorm backward are summed across the pair through LDS behind one extra barrier per pass.
+template <int KP>
+__global__ __launch_bounds__(512) void rowgemm_lnbwd8_kernel(const mmfm_rowgemm_desc d) {
+    constexpr int NT = 512, NW = 8, NPAIR = 4;
+    __shared__ __attribute__((aligned(16))) char smem[2 * CHUNK2 + NW * STG_BYTES + NW * 32 * 8];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
+    const int half = wave >> 2, pw = wave & 3;
+    constexpr int cpp = 4 * KP;
+    const int64_t npass = (d.R + 32 * NPAIR - 1) / (32 * NPAIR);
+    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
+    if (my_passes == 0) return;
+    const uint16_t* W = reinterpret_cast<const uint16_t*>(d.w);
+    const int ldw = d.ldw;
+    auto src = [=](int g) {
+        const int idx = g % cpp, p = idx >> 2, j = idx & 3;
+        WChunk2 c;
+        c.s[0].base = W + (size_t)(32 * j) * ldw + 256 * p; c.s[0].ld = ldw; c.s[0].kind = 0;
+        c.s[1].base = W + (size_t)(32 * (4 + j)) * ldw + 256 * p; c.s[1].ld = ldw; c.s[1].kind = 0;
+        return c;
+    };
+    char* stg = smem + 2 * CHUNK2 + wave * STG_BYTES;
+    float2* exch = reinterpret_cast<float2*>(smem + 2 * CHUNK2 + NW * STG_BYTES);      // [wave][32 rows]
+    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), RES = gbuf(d.residual, d.R * d.ldr * 2);
+    const GBuf XH = gbuf(d.bwd_xhat, d.R * 512), RS = gbuf(d.bwd_rstd, d.R * 4);
+    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2, ldrb = d.ldr * 2;
+    RING2_DECL(NT);
+    RING2_START(smem, my_passes * cpp, src);
+    for (int pi = 0; pi < my_passes; ++pi) {
+        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NPAIR + pw) * 32);
+        const bool live = wrow0 < (uint32_t)d.R;
+        f32x16 acc[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = zero16();
+        Lines L[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) L[q] = fetch_lines(X, wrow0, ldxb, 128u * q, lane);
+#pragma unroll
+        for (int p = 0; p < KP; ++p) {
+            opnd x[16];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                stage_lines(stg, L[q], lane);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) x[4 * q + s4] = unstage_opnd(stg, s4, m, h);
+                if (p + 1 < KP) L[q] = fetch_lines(X, wrow0, ldxb, 512u * (p + 1) + 128u * q, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const char* slot;
+                RING2_STEP(src, slot);
+                if (live) acc[j] = mma16<4>(slot + half * CHUNK, x, acc[j], m, h);
+            }
+        }
+        // this wave's columns: tiles 4*half .. 4*half+3 = line pairs 2*half, 2*half+1
+        f32x16 xt[4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const Lines xl = fetch_lines(XH, wrow0, 512u, 128u * (2 * half + q), lane);
+            stage_lines(stg, xl, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                xt[2 * q + j] = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s1 += acc[2 * q + j][i]; s2 = fmaf(acc[2 * q + j][i], xt[2 * q + j][i], s2); }
+            }
+        }
+        s1 = xhalf(s1); s2 = xhalf(s2);
+        if (h == 0) exch[wave * 32 + m] = make_float2(s1, s2);
+        __syncthreads();
+        const float2 o2 = exch[(wave ^ 4) * 32 + m];
+        s1 = (s1 + o2.x) * (1.f / 256.f);
+        s2 = (s2 + o2.y) * (1.f / 256.f);
+        const float rs = ld4f(RS, (wrow0 + m) * 4u);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const Lines rl = fetch_lines(RES, wrow0, ldrb, 128u * (2 * half + q), lane);
+            stage_lines(stg, rl, lane);
+            f32x16 o[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 r = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[j][i] = r[i] + rs * (acc[2 * q + j][i] - s1 - xt[2 * q + j][i] * s2);
+            }
+            stage_tile(stg, 0, m, h, o[0]);
+            stage_tile(stg, 1, m, h, o[1]);
+            flush_lines<false>(stg, Y, wrow0, ldyb, 128u * (2 * half + q), lane);
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ weight preparation
 // One block per (entry, 32-row tile of W): Wp = bf16(W * gamma[k]) [N][K], WpT = its transpose [K][N],
 // bp[n] = bias[n] + sum_k W[n][k] * beta[k]  (the LayerNorm affine folded into the linear it feeds).
@@ -247,26 +511,58 @@ extern "C" int mmfm_rowgemm(const mmfm_rowgemm_desc* dp, mmfm_stream stream) {
     const int64_t maxld = std::max<int64_t>(std::max(d.ldx, d.ldy), std::max(d.ldr, 256));
     MMFM_REQUIRE((d.R + 128) * maxld * 2 < (int64_t)1 << 31, "mmfm_rowgemm: tensors beyond 2 GiB are not addressable by the 32-bit buffer offsets");
     MMFM_REQUIRE(d.N <= BIAS_MAX, "mmfm_rowgemm: N = %d > %d", d.N, BIAS_MAX);
+    // Variant selection (measured on MI355X at R = 204,800, scripts/rowchain_bench.py):
+    //   forward-type K = 256 : v1 = 4 waves x 2 workgroups per CU (default: LN+q 78 us, LN+kv 117 us, out_proj 71 us);
+    //                          v8 = 8 waves, 32 KB chunks, skewed wave groups; v7 = 7 compute waves + 1 weight-stager wave
+    //   LN-backward epilogue : K = 256 -> wave pairs (8 waves, 101 us); K = 512 / 768 -> one wave per row tile (172 / 284 us)
     static const int per_cu_env = [] { const char* e = getenv("MMFM_ROWGEMM_WG_PER_CU"); return e ? atoi(e) : 0; }();
+    static const int variant = [] { const char* e = getenv("MMFM_ROWGEMM_VARIANT"); return e ? atoi(e) : 1; }();   // 1, 7, 8 (18 = v1 with 8 waves)
+    static const int lb_pairs = [] { const char* e = getenv("MMFM_LNBWD_PAIRS"); return e ? atoi(e) : 256; }();      // largest K that uses wave pairs
     hipStream_t st = (hipStream_t)stream;
     if (d.ln_bwd) {
         MMFM_REQUIRE(d.N == 256 && d.bwd_xhat && d.bwd_rstd && !d.ln && !d.bias, "mmfm_rowgemm: ln_bwd needs N = 256, x_hat, rstd, no bias/ln");
-        dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1)), block(NT);
-        if (d.K == 256) hipLaunchKernelGGL(rowgemm_lnbwd_kernel<1>, grid, block, 0, st, d);
-        else if (d.K == 512) hipLaunchKernelGGL(rowgemm_lnbwd_kernel<2>, grid, block, 0, st, d);
-        else hipLaunchKernelGGL(rowgemm_lnbwd_kernel<3>, grid, block, 0, st, d);
+        if (d.K <= lb_pairs) {
+            dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, 4)), block(512);      // 4 row tiles (wave pairs) per pass
+            if (d.K == 256) hipLaunchKernelGGL(rowgemm_lnbwd8_kernel<1>, grid, block, 0, st, d);
+            else if (d.K == 512) hipLaunchKernelGGL(rowgemm_lnbwd8_kernel<2>, grid, block, 0, st, d);
+            else hipLaunchKernelGGL(rowgemm_lnbwd8_kernel<3>, grid, block, 0, st, d);
+        } else {
+            dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1)), block(NT);
+            if (d.K == 256) hipLaunchKernelGGL(rowgemm_lnbwd_kernel<1>, grid, block, 0, st, d);
+            else if (d.K == 512) hipLaunchKernelGGL(rowgemm_lnbwd_kernel<2>, grid, block, 0, st, d);
+            else hipLaunchKernelGGL(rowgemm_lnbwd_kernel<3>, grid, block, 0, st, d);
+        }
     } else {
-        static const int nw_env = [] { const char* e = getenv("MMFM_ROWGEMM_WAVES"); return e ? atoi(e) : 0; }();
-        const int nw = d.K == 256 ? (nw_env == 4 ? 4 : 8) : 4;           // K = 256: 8 waves (<= 256 registers each)
-        dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, nw)), block(nw * 64);
 #define RG_LAUNCH(KP, LN, NWV)                                                                               \
     if (d.stream_out) hipLaunchKernelGGL((rowgemm_kernel<KP, LN, true, NWV>), grid, block, 0, st, d);        \
     else hipLaunchKernelGGL((rowgemm_kernel<KP, LN, false, NWV>), grid, block, 0, st, d);
-        if (d.ln) { if (nw == 8) { RG_LAUNCH(1, true, 8) } else { RG_LAUNCH(1, true, 4) } }
-        else if (d.K == 256) { if (nw == 8) { RG_LAUNCH(1, false, 8) } else { RG_LAUNCH(1, false, 4) } }
-        else if (d.K == 512) { RG_LAUNCH(2, false, 4) }
-        else { RG_LAUNCH(3, false, 4) }
+#define RG8_LAUNCH(LN, NTS)                                                                                  \
+    if (d.residual) hipLaunchKernelGGL((rowgemm8_kernel<LN, NTS, true>), grid, block, 0, st, d);             \
+    else hipLaunchKernelGGL((rowgemm8_kernel<LN, NTS, false>), grid, block, 0, st, d);
+#define RG7_LAUNCH(LN, NTS)                                                                                  \
+    if (d.residual) hipLaunchKernelGGL((rowgemm7_kernel<LN, NTS, true>), grid, block, 0, st, d);             \
+    else hipLaunchKernelGGL((rowgemm7_kernel<LN, NTS, false>), grid, block, 0, st, d);
+        if (d.K != 256) {
+            dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, 4)), block(256);
+            if (d.K == 512) { RG_LAUNCH(2, false, 4) } else { RG_LAUNCH(3, false, 4) }
+        } else if (variant == 7) {
+            dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, 7)), block(512);
+            if (d.ln) { if (d.stream_out) { RG7_LAUNCH(true, true) } else { RG7_LAUNCH(true, false) } }
+            else { if (d.stream_out) { RG7_LAUNCH(false, true) } else { RG7_LAUNCH(false, false) } }
+        } else if (variant == 8) {
+            dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, 8)), block(512);
+            if (d.ln) { if (d.stream_out) { RG8_LAUNCH(true, true) } else { RG8_LAUNCH(true, false) } }
+            else { if (d.stream_out) { RG8_LAUNCH(false, true) } else { RG8_LAUNCH(false, false) } }
+        } else if (variant == 18) {
+            dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, 8)), block(512);
+            if (d.ln) { RG_LAUNCH(1, true, 8) } else { RG_LAUNCH(1, false, 8) }
+        } else {
+            dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 2, 4)), block(256);
+            if (d.ln) { RG_LAUNCH(1, true, 4) } else { RG_LAUNCH(1, false, 4) }
+        }
 #undef RG_LAUNCH
+#undef RG8_LAUNCH
+#undef RG7_LAUNCH
     }
     MMFM_LAUNCH_CHECK("mmfm_rowgemm");
     return 0;

@@ -303,7 +303,7 @@ class Engine:
         c = self.cfg
         if self.dtype != "bf16" or c.hidden != 256 or c.inter != 512 or (R + 128) * 1024 * 2 >= 2 ** 31:
             return 0
-        return int(os.environ.get("MMFM_FUSED", "15")) & 15
+        return int(os.environ.get("MMFM_FUSED", "10")) & 15        # default: the group that measures faster end to end
 
     def _build_prep(self):
         """Prepared weights of the fused path: per LayerNorm-fed linear Wp = bf16(W * gamma), WpT, bp = b + W beta
@@ -457,6 +457,9 @@ class Engine:
         if fm:
             K.prep_weights(prep["table"], prep["n"], prep["tiles"], plan=fwd)
             gdb = buf("ws/gdb", (max(_align(mm * nn + mm) for mm, nn in ((3 * H, H), (2 * H, H), (I, H), (H, H))),), f32)
+            if "ws/lng" not in self.b:
+                self.b["ws/lng"] = K.ln_linear_grad_workspace(H, self.device)          # zeroed once; the kernel re-arms its tickets
+            ws_lng = self.b["ws/lng"]
 
         def ln_lin(plan, Xin, lnname, wname, Yout, N, tag, residual=None):
             """LayerNorm + the linear it feeds in one launch; x_hat / rstd saved for the backward when training."""
@@ -480,7 +483,7 @@ class Engine:
                 K.reduce_slabs(gdb, slab, N * H + N, S, stride, plan=plan)
             K.ln_linear_grad(gdb, self.Pf(wname + ".weight"), self.Pf(lnname + ".weight"), self.Pf(lnname + ".bias"), N, H,
                              self.Gv(wname + ".weight"), self.Gv(wname + ".bias"), self.Gv(lnname + ".weight"), self.Gv(lnname + ".bias"),
-                             plan=plan)
+                             ws_lng, plan=plan)
 
         def dx_ln(plan, dYt, Kd, tag, wname, dres, dXout):
             """dX of a LayerNorm-fed linear with the LayerNorm backward (and the residual gradient) in its epilogue."""

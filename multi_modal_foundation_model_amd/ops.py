@@ -212,5 +212,11 @@ def mlp_bwd(desc, plan=None):
     _emit(plan, L.lib().mmfm_mlp_bwd, (C.byref(desc),), keep=(desc,))
 
 
-def ln_linear_grad(Gdb, W, gamma, beta, N, K, dW, dbias, dgamma, dbeta, accumulate_ln=False, plan=None):
-    _emit(plan, L.lib().mmfm_ln_linear_grad, (P(Gdb), P(W), P(gamma), P(beta), N, K, P(dW), P(dbias), P(dgamma), P(dbeta), int(accumulate_ln)))
+def ln_linear_grad_workspace(K, device):
+    """Zeroed workspace of mmfm_ln_linear_grad (partials + self re-arming tickets)."""
+    return torch.zeros(L.lib().mmfm_ln_linear_grad_workspace(K) // 4, dtype=torch.float32, device=device)
+
+
+def ln_linear_grad(Gdb, W, gamma, beta, N, K, dW, dbias, dgamma, dbeta, ws, accumulate_ln=False, plan=None):
+    _emit(plan, L.lib().mmfm_ln_linear_grad, (P(Gdb), P(W), P(gamma), P(beta), N, K, P(dW), P(dbias), P(dgamma), P(dbeta), int(accumulate_ln),
+                                              P(ws), ws.numel() * 4), keep=(ws,))

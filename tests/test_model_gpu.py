@@ -429,9 +429,10 @@ def test_bf16_fused_row_owner_path_matches_unfused_kernels(monkeypatch):
             assert n1 == pytest.approx(n0, rel=5e-2), f"{obj} {k}: norm {n1} vs {n0}"
 
 
-def test_bf16_fused_path_trains_with_dropout_and_partial_rows():
+def test_bf16_fused_path_trains_with_dropout_and_partial_rows(monkeypatch):
     """Dropout as configured, B = 5 (R = 1000 rows: not a multiple of the 128 / 256-row passes) and padded trials: a few
     optimiser steps stay finite and reduce the loss; a second engine with the same seed reproduces them bit for bit."""
+    monkeypatch.setenv("MMFM_FUSED", "15")           # every fused group, not only the default one
     mc = model_config(n_enc=2, n_dec=2)
     curves = []
     for rep in range(2):

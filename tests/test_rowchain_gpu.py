@@ -194,11 +194,12 @@ def test_ln_linear_grad_matches_autograd(ops):
     xhat = F.layer_norm(x, (K,), None, None, 1e-5)
     Gdb = torch.cat([(dY.T @ xhat).flatten(), dY.sum(0)]).float().contiguous()
     dW, db, dg, dbt = torch.empty(N, K, device="cuda"), torch.empty(N, device="cuda"), torch.ones(K, device="cuda"), torch.ones(K, device="cuda")
-    ops.ln_linear_grad(Gdb, W.detach().float().contiguous(), g.detach().float().contiguous(), bt.detach().float().contiguous(), N, K, dW, db, dg, dbt)
+    ws = ops.ln_linear_grad_workspace(K, "cuda")
+    ops.ln_linear_grad(Gdb, W.detach().float().contiguous(), g.detach().float().contiguous(), bt.detach().float().contiguous(), N, K, dW, db, dg, dbt, ws)
     torch.testing.assert_close(dW.double(), W.grad, rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(db.double(), bias.grad, rtol=1e-5, atol=1e-5)
     torch.testing.assert_close(dg.double(), g.grad, rtol=1e-4, atol=2e-4)
     torch.testing.assert_close(dbt.double(), bt.grad, rtol=1e-4, atol=2e-4)
     ops.ln_linear_grad(Gdb, W.detach().float().contiguous(), g.detach().float().contiguous(), bt.detach().float().contiguous(), N, K, dW, db, dg, dbt,
-                       accumulate_ln=True)
+                       ws, accumulate_ln=True)                                      # same workspace: the tickets re-armed themselves
     torch.testing.assert_close(dg.double(), 2 * g.grad, rtol=1e-4, atol=4e-4)
