@@ -50,10 +50,36 @@ class FusedAdamW(torch.optim.Optimizer):
             raise RuntimeError("FusedAdamW must own exactly the engine's parameters (model.parameters())")
         return eng
 
+    # ------------------------------------------------------------------ checkpoint (resume, absent upstream)
+    def state_dict(self):
+        """torch's state_dict plus the fused state: step count and the flat first / second moment buffers (engine layout).
+        Without them a resume would restart the bias correction at t = 1 with zero moments."""
+        sd = super().state_dict()
+        sd["fused"] = dict(t=self._t, m=None if self._m is None else self._m.detach().cpu().clone(),
+                           v=None if self._v is None else self._v.detach().cpu().clone())
+        return sd
+
+    def load_state_dict(self, state_dict):
+        fused = state_dict.get("fused")
+        super().load_state_dict({k: v for k, v in state_dict.items() if k != "fused"})
+        if fused is None:
+            raise KeyError("FusedAdamW.load_state_dict: no 'fused' entry (moments / step count): not a FusedAdamW checkpoint")
+        self._t = int(fused["t"])
+        if fused["m"] is not None:
+            eng = self._bind()
+            if fused["m"].numel() != eng.P.numel():
+                raise ValueError(f"checkpoint moments have {fused['m'].numel()} elements, the engine's flat buffer {eng.P.numel()}")
+            self._m.copy_(fused["m"].to(self._m.device))
+            self._v.copy_(fused["v"].to(self._v.device))
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         eng = self._bind()
+        # torch skips parameters whose .grad is None: after zero_grad() and before the next backward that is all of them
+        # (the flat gradient buffer still holds the previous step's values - they must not be applied twice)
+        if all(p.grad is None for p in self.param_groups[0]["params"]):
+            return loss
         for hook in self.pre_step_hooks:
             hook()
         g = self.param_groups[0]

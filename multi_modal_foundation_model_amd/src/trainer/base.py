@@ -262,7 +262,46 @@ class MultiModalTrainer():
         return {"plot_gt_pred": fig, "plot_r2": r2_fig}
 
     def save_model(self, name="last", epoch=0):
-        """Whole-module pickle like the reference (trainer/base.py:302-308) so its eval scripts can load it."""
+        """Whole-module pickle like the reference (trainer/base.py:302-308) so its eval scripts can load it; next to it the
+        training state the reference never saves (optimiser moments + step, OneCycleLR, dropout / masker / objective RNG) so
+        that a run can RESUME: `load_train_state`."""
         print(f"saving model: {name} to {self.log_dir}")
         model = getattr(self.model, "module", self.model)
         torch.save({"model": model, "epoch": epoch}, os.path.join(self.log_dir, f"model_{name}.pt"))
+        self.save_train_state(name=name, epoch=epoch)
+
+    def train_state_path(self, name="last"):
+        return os.path.join(self.log_dir, f"train_state_{name}.pt")
+
+    def save_train_state(self, name="last", epoch=0):
+        model = getattr(self.model, "module", self.model)
+        eng = getattr(model, "_engine", None)
+        state = dict(epoch=epoch, optimizer=self.optimizer.state_dict(),
+                     lr_scheduler=self.lr_scheduler.state_dict() if self.lr_scheduler is not None else None,
+                     engine_rng=None if eng is None else eng.rng.detach().cpu().clone(),
+                     engine_dtype=None if eng is None else eng.dtype,
+                     torch_rng=torch.get_rng_state(), python_rng=random.getstate(), numpy_rng=np.random.get_state(),
+                     masker=dict(mode=model.masker.mode, ratio=model.masker.ratio, mask_regions=model.masker.mask_regions,
+                                 target_regions=model.masker.target_regions) if hasattr(model, "masker") else None,
+                     session_active_neurons=list(self.session_active_neurons))
+        torch.save(state, self.train_state_path(name))
+
+    def load_train_state(self, path=None, name="last"):
+        """Restore what `save_train_state` wrote into THIS trainer (model parameters come from the module pickle or a
+        state_dict the caller loaded; the engine is created on the spot so the flat buffers exist).  Returns the epoch."""
+        state = torch.load(path or self.train_state_path(name), weights_only=False)        # our own file
+        model = getattr(self.model, "module", self.model)
+        eng = model.engine()
+        self.optimizer.load_state_dict(state["optimizer"])
+        if self.lr_scheduler is not None and state["lr_scheduler"] is not None:
+            self.lr_scheduler.load_state_dict(state["lr_scheduler"])
+        if state["engine_rng"] is not None:
+            eng.rng.copy_(state["engine_rng"].to(eng.rng.device))
+        torch.set_rng_state(state["torch_rng"])
+        random.setstate(state["python_rng"])
+        np.random.set_state(state["numpy_rng"])
+        if state.get("masker") and hasattr(model, "masker"):
+            for k, v in state["masker"].items():
+                setattr(model.masker, k, v)
+        self.session_active_neurons = list(state.get("session_active_neurons", []))
+        return state["epoch"]

@@ -648,13 +648,135 @@ def fx_eval_metrics():
     save_npz("eval_metrics.npz", **arrs)
 
 
+def fx_masker_modes():
+    """Every Masker mode (models/masker.py:78-168) beyond `temporal`: returned spikes AND target masks, plus the generator
+    state afterwards (torch CPU generator and Python's `random`, which the region modes draw from)."""
+    base = plain(ref_config()["model"]["masker"])
+    regions_row = ["CA1", "PO", "CA1", "LP", "PO", "CA1", "LP", "PO", "DG"]
+    cases_in = [
+        dict(mode="neuron", ratio=0.3),
+        dict(mode="random", ratio=0.2),
+        dict(mode="co-smooth", ratio=0.3, channels=[1, 4, 7]),
+        dict(mode="forward-pred", ratio=0.3, timesteps=[15, 16, 17, 18, 19]),
+        dict(mode="inter-region", ratio=0.3, mask_regions=["CA1", "PO", "LP"], target_regions=["all"], n_mask_regions=2),
+        dict(mode="intra-region", ratio=0.4, mask_regions=["all"], target_regions=["CA1", "PO"], n_mask_regions=1),
+        dict(mode="causal", ratio=0.3, max_timespan=3, causal_zero=True),
+        dict(mode="causal", ratio=0.3, max_timespan=2, causal_zero=False),
+        dict(mode="temporal", ratio=0.3, expand_prob=1.0, max_timespan=4, zero_ratio=0.7, random_ratio=0.5),
+        dict(mode="neuron", ratio=0.5, zero_ratio=0.5, random_ratio=1.0),
+    ]
+    arrs, cases = {}, []
+    for cid, kw in enumerate(cases_in):
+        mc = dict(base, **kw)
+        mk = Masker(DictConfig(mc))
+        mk.train()
+        torch.manual_seed(3 + cid)
+        random.seed(17 + cid)
+        g = torch.Generator().manual_seed(200 + cid)
+        ap = torch.poisson(torch.full((4, 20, 9), 0.6), generator=g)
+        regions = np.asarray([regions_row] * 4)
+        out1, m1 = mk(ap.clone(), regions)
+        out2, m2 = mk(ap.clone(), regions)               # second call: generator / `random` consumption order
+        arrs[f"c{cid}/ap"] = npify(ap)
+        arrs[f"c{cid}/out1"], arrs[f"c{cid}/mask1"] = npify(out1), npify(m1)
+        arrs[f"c{cid}/out2"], arrs[f"c{cid}/mask2"] = npify(out2), npify(m2)
+        arrs[f"c{cid}/after"] = npify(torch.rand(3))
+        cases.append(dict(id=cid, cfg=mc, after_random=random.random(), regions=regions_row))
+    arrs["meta"] = np.frombuffer(json.dumps(cases).encode(), dtype=np.uint8)
+    save_npz("masker_modes.npz", **arrs)
+
+
+def fx_loss_curve_1k_default():
+    """The north star's curve at the metric's own config: d_model 256, 5+5 layers, T=100, 668+2 channels, B=16, dropout 0,
+    1000 optimisation steps of the reference on the CPU (mixed objectives, OneCycleLR over the 1000 steps)."""
+    cfg = plain(ref_config()["model"])
+    for side in ("encoder", "decoder"):
+        cfg[side]["embedder"]["dropout"] = 0.0
+        cfg[side]["transformer"]["dropout"] = 0.0
+    model = build_model(DictConfig(cfg), 668, 2, seed=42)
+    l, o = run_curve(model, 1000, 16, 100, 668, 2, total_steps=1000)
+    print("    default 1k curve:", l[:2], "...", l[-2:])
+    save_json("loss_curve_1k_default.json", dict(loss=l, objective=o, model_seed=42, B=16, T=100, n_ap=668, n_beh=2, total_steps=1000))
+
+
+def fx_h64_curve():
+    """BASELINE.json configs[0] as worded ("2-layer d_model=64"): MultiModal with 2+2 layers, hidden 64, 8 heads, inter 128, on the
+    reference's CPU path: per-objective scalars (loss, n, every gradient norm) and a 100-step curve."""
+    mc = tiny_model_cfg(H=64, heads=8, inter=128, n_enc=2, n_dec=2, max_F=100)
+    model = build_model(mc, 668, 2, seed=11)
+    batch = synth_batch(16, 100, 668, 2, seed=0)
+    res = dict(model_seed=11, B=16, T=100, n_ap=668, n_beh=2, scalars={})
+    model.eval()
+    for obj in ("encoding", "decoding", "token_masking"):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(1)
+        out = model(make_mod_dict(batch, obj))
+        out.loss.backward()
+        res["scalars"][obj] = dict(loss=float(out.loss), n={m: int(v) for m, v in out.mod_n_examples.items()},
+                                   pred_abssum={m: float(v.double().abs().sum()) for m, v in out.mod_preds.items()},
+                                   grad_norm={k: float(p.grad.double().norm()) for k, p in model.named_parameters()})
+    model = build_model(mc, 668, 2, seed=11)
+    l, o = run_curve(model, 100, 16, 100, 668, 2, total_steps=100)
+    res.update(loss=l, objective=o, total_steps=100)
+    print("    h64 curve:", l[:2], "...", l[-1])
+    save_json("h64_curve.json", res)
+
+
+MULTISESSION_BIG = dict(sessions=40, trials=4, T=100, max_N=668, lo=300, pad=-1.0, model_seed=42, neuron_seed=2024)
+
+
+def fx_multisession_big():
+    """BASELINE configs[2] at its stated size: 40 sessions of 300-668 neurons, single-session batches right-padded
+    with -1 to 668 by the reference's own loader, default model (d_model 256, dropout 0), one pass over the sessions."""
+    import datasets
+    if not hasattr(datasets, "list_datasets"):
+        datasets.list_datasets = lambda *a, **k: []
+    from loader.make_loader import make_loader
+    sys.path.insert(0, os.path.join(REPO, "oracle"))
+    import loader_oracle as LO
+    ms = MULTISESSION_BIG
+    rng = np.random.default_rng(ms["neuron_seed"])
+    neurons = [int(x) for x in rng.integers(ms["lo"], ms["max_N"] + 1, ms["sessions"])]
+    cfg = plain(ref_config()["model"])
+    for side in ("encoder", "decoder"):
+        cfg[side]["embedder"]["dropout"] = 0.0
+        cfg[side]["transformer"]["dropout"] = 0.0
+    model = build_model(DictConfig(cfg), ms["max_N"], 2, seed=ms["model_seed"])
+    opt, sch = make_opt(model, ms["sessions"])
+    model.train()
+    batches = []
+    for s_id, n in enumerate(neurons):
+        trials = LO.synth_session_trials(n, ms["trials"], ms["T"], seed=500 + s_id, eid=f"session{s_id}")
+        ld = make_loader(trials, batch_size=ms["trials"], target=["wheel-speed", "whisker-motion-energy"], pad_value=ms["pad"],
+                         max_time_length=ms["T"], max_space_length=ms["max_N"], load_meta=True, shuffle=False)
+        batches.append(next(iter(ld)))
+    random.seed(42)
+    torch.manual_seed(1234)
+    losses, objs, ns = [], [], []
+    for step, batch in enumerate(batches):
+        obj = random.sample(["encoding", "decoding", "token_masking"], 1)[0]
+        regions = np.asarray(batch["neuron_regions"]).T
+        b = dict(spikes_data=batch["spikes_data"].float(), target=batch["target"].float(), time_attn_mask=batch["time_attn_mask"],
+                 spikes_timestamps=batch["spikes_timestamps"])
+        out = model(make_mod_dict(b, obj, regions=regions))
+        out.loss.backward()
+        opt.step(); sch.step(); opt.zero_grad()
+        losses.append(float(out.loss.detach()))
+        objs.append(obj)
+        ns.append({k: int(v) for k, v in out.mod_n_examples.items()})
+    print("    multisession (40 sessions) curve:", losses[:3], "...", losses[-1])
+    save_json("multisession_big.json", dict(ms, neurons=neurons, loss=losses, objective=objs, n=ns,
+                                            final_norm={k: float(v.double().norm()) for k, v in model.state_dict().items()}))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in [("init_order", fx_init_order), ("tiny_fwd_bwd", fx_tiny_fwd_bwd),
                      ("default_scalars", fx_default_scalars), ("masker_bits", fx_masker_bits),
                      ("mask_index_ops", fx_mask_index_ops), ("sched_adamw", fx_sched_adamw),
-                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("multisession_curve", fx_multisession_curve), ("eval_metrics", fx_eval_metrics), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate)]:
+                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("multisession_curve", fx_multisession_curve), ("eval_metrics", fx_eval_metrics), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate), ("masker_modes", fx_masker_modes),
+                     ("h64_curve", fx_h64_curve), ("multisession_big", fx_multisession_big), ("loss_curve_1k_default", fx_loss_curve_1k_default)]:
         if only and name not in only:
             continue
         print(f"[{name}]")

@@ -127,3 +127,54 @@ def test_multisession_gpu_collate_and_model_vs_reference_fixture():
     np.testing.assert_allclose([x.item() for x in losses], g["loss"], rtol=1e-4)
     for k, v in model.state_dict().items():
         assert float(v.double().norm()) == pytest.approx(g["final_norm"][k], rel=1e-4, abs=1e-7), k
+
+
+# ------------------------------------------------------------------ BASELINE configs[2] at its stated size: 40 sessions, 300-668 neurons
+def _big_sessions(g, upto=None):
+    return [LO.synth_session_trials(n, g["trials"], g["T"], seed=500 + i, eid=f"session{i}") for i, n in enumerate(g["neurons"][:upto])]
+
+
+def test_multisession_big_oracle_prefix_vs_reference_fixture():
+    """40 sessions of 300-668 neurons right-padded with -1 to 668, default model (oracle/make_goldens.py:fx_multisession_big):
+    the oracle's loader + model restatement replays the first steps of the reference's pass over the sessions."""
+    import torch
+    from oracle import mm_oracle as O
+    from test_oracle_golden import default_masker_cfg
+    g = load_json("multisession_big.json")
+    assert len(g["neurons"]) == 40 and min(g["neurons"]) >= 300 and max(g["neurons"]) <= 668
+    cfg = O.OracleCfg(embed_dropout=0.0, dropout=0.0)
+    tr = O.OracleTrainer(O.init_state_dict(cfg, seed=g["model_seed"]), cfg, default_masker_cfg(), total_steps=g["sessions"])
+    torch.manual_seed(1234)
+    for s, trials in enumerate(_big_sessions(g, upto=3)):
+        nb = LO.collate(trials, TARGET, g["T"], g["max_N"], g["pad"])
+        batch = dict(spikes_data=torch.from_numpy(nb["spikes_data"]), target=torch.from_numpy(nb["target"]).float(),
+                     time_attn_mask=torch.from_numpy(nb["time_attn_mask"]), spikes_timestamps=torch.from_numpy(nb["spikes_timestamps"]))
+        assert tr.step(batch, g["objective"][s]).item() == pytest.approx(g["loss"][s], rel=1e-4), s
+
+
+@pytest.mark.gpu
+def test_multisession_big_gpu_vs_reference_fixture():
+    """All 40 steps on the MI355X in fp32 parity mode: device-side collate of every session, loss curve (rtol 1e-4), the exact
+    masked-element counts and the final parameter norms against the reference's run."""
+    import torch
+    from helpers import build_model, make_optimizer, model_config
+    from multi_modal_foundation_model_amd.collate import collate_ibl_trials
+    from oracle import mm_oracle as O
+    g = load_json("multisession_big.json")
+    model = build_model(model_config(dropout=0.0, emb_dropout=0.0), g["max_N"], 2, seed=g["model_seed"]).cuda().train()
+    opt, sch = make_optimizer(model, g["sessions"])
+    torch.manual_seed(1234)
+    losses = []
+    for s, trials in enumerate(_big_sessions(g)):
+        batch = collate_ibl_trials(trials, TARGET, g["T"], g["max_N"], g["pad"], device="cuda")
+        md = O.make_mod_dict({k: batch[k] for k in ("spikes_data", "target", "time_attn_mask", "spikes_timestamps")}, g["objective"][s])
+        for d in md.values():
+            d["targets_modality"], d["targets_timestamp"] = d["inputs_modality"], d["inputs_timestamp"]
+        out = model(md)
+        out.loss.backward()
+        opt.step(); sch.step(); opt.zero_grad()
+        losses.append(out.loss.detach())
+        assert {k: int(v) for k, v in out.mod_n_examples.items()} == g["n"][s]
+    np.testing.assert_allclose([x.item() for x in losses], g["loss"], rtol=1e-4)
+    for k, v in model.state_dict().items():
+        assert float(v.double().norm()) == pytest.approx(g["final_norm"][k], rel=1e-4, abs=1e-7), k

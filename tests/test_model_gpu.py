@@ -163,6 +163,56 @@ def test_loss_curve_default_30_steps_vs_reference_fixture():
     np.testing.assert_allclose(losses, g["loss"], rtol=1e-4)
 
 
+def test_h64_two_layer_config_vs_reference_fixture():
+    """BASELINE.json configs[0] as worded: 2+2 layers, d_model 64, 8 heads, inter 128 (fx_h64_curve): per-objective loss, exact n,
+    every gradient norm, and the 100-step curve in fp32 parity mode."""
+    g = load_json("h64_curve.json")
+    mc = model_config(H=64, heads=8, inter=128, n_enc=2, n_dec=2, max_F=100, dropout=0.0, emb_dropout=0.0)
+    model = build_model(mc, 668, 2, seed=g["model_seed"]).cuda().eval()
+    batch = O.synth_batch(16, 100, 668, 2, seed=0)
+    for obj in ("encoding", "decoding", "token_masking"):
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(1)
+        out = model(to_dev(O.make_mod_dict(batch, obj)))
+        out.loss.backward()
+        s = g["scalars"][obj]
+        assert out.loss.item() == pytest.approx(s["loss"], rel=1e-5)
+        for m in ("ap", "behavior"):
+            assert int(out.mod_n_examples[m]) == s["n"][m]
+            assert float(out.mod_preds[m].double().abs().sum()) == pytest.approx(s["pred_abssum"][m], rel=1e-4)
+        for k, prm in model.named_parameters():
+            assert float(prm.grad.double().norm()) == pytest.approx(s["grad_norm"][k], rel=5e-3, abs=1e-8), k
+    model = build_model(mc, 668, 2, seed=g["model_seed"]).cuda()
+    losses = run_curve(model, 100, 16, 100, 668, 2, 100, g["objective"])
+    np.testing.assert_allclose(losses, g["loss"], rtol=1e-4)
+
+
+def test_loss_curve_default_1000_steps_fp32_vs_reference_fixture():
+    """North star at the metric's own config: d_model 256, 5+5 layers, T=100, 668+2 channels, B=16, dropout 0, mixed objectives,
+    OneCycleLR over the run - all 1000 steps of the reference's CPU curve (fx_loss_curve_1k_default) within rtol 1e-4 in fp32
+    parity mode."""
+    g = load_json("loss_curve_1k_default.json")
+    model = build_model(model_config(dropout=0.0, emb_dropout=0.0), 668, 2, seed=42).cuda()
+    losses = run_curve(model, 1000, 16, 100, 668, 2, 1000, g["objective"])
+    np.testing.assert_allclose(losses, g["loss"], rtol=1e-4)
+
+
+def test_loss_curve_default_1000_steps_bf16_drift_bound():
+    """The same 1000 steps in bf16 throughput mode (the benched mode, fused row-owner kernels on).  Stated and tested bound against
+    the fp32 reference curve: every step within 2e-2 relative, every 50-step window mean within 5e-3 relative."""
+    g = load_json("loss_curve_1k_default.json")
+    model = build_model(model_config(dropout=0.0, emb_dropout=0.0), 668, 2, seed=42)
+    model.compute_dtype = "bf16"
+    model.cuda()
+    losses = np.asarray(run_curve(model, 1000, 16, 100, 668, 2, 1000, g["objective"]))
+    ref = np.asarray(g["loss"])
+    assert np.isfinite(losses).all()
+    rel = np.abs(losses - ref) / np.abs(ref)
+    assert rel.max() < 2e-2, f"worst step {int(rel.argmax())}: {losses[rel.argmax()]} vs {ref[rel.argmax()]}"
+    win = np.abs(losses.reshape(20, 50).mean(1) - ref.reshape(20, 50).mean(1)) / ref.reshape(20, 50).mean(1)
+    assert win.max() < 5e-3, f"window {int(win.argmax())}: {win.max()}"
+
+
 def test_adamw_trajectory_vs_reference_fixture():
     z, _ = load_npz("sched_adamw.npz")
     model = build_model(tiny_config(), 12, 2, seed=7).cuda()
@@ -452,3 +502,72 @@ def test_bf16_fused_path_trains_with_dropout_and_partial_rows(monkeypatch):
         curves.append(losses)
     assert np.isfinite(curves[0]).all() and curves[0] == curves[1]
     assert curves[0][4] < curves[0][0]
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_resume_from_train_state_is_bit_identical(tmp_path, dtype):
+    """6 steps in one go == 3 steps, save_model (module pickle + train state), brand-new model / optimiser /
+    scheduler / trainer objects restored from the files, 3 more steps.  Dropout is on (engine RNG), objectives are sampled
+    (Python RNG) and token_masking draws masks (torch RNG): all three streams must continue exactly."""
+    from trainer.make import make_multimodal_trainer
+    from multi_modal_foundation_model_amd.ddp import Accelerator
+    B, T, n_ap, n_beh = 4, 8, 12, 2
+    mc = tiny_config(n_enc=2, n_dec=2, dropout=0.4, emb_dropout=0.2)
+
+    def batches(lo, hi):
+        out = []
+        for i in range(lo, hi):
+            b = O.synth_batch(B, T, n_ap, n_beh, seed=i)
+            b["eid"] = ["synthetic"] * B
+            b["neuron_regions"] = [["XX"] * B for _ in range(n_ap)]
+            out.append(b)
+        return out
+
+    def make(model, loader, log_dir):
+        model.compute_dtype = dtype
+        acc = Accelerator()
+        model = acc.prepare(model)
+        opt, sch = make_optimizer(model, 40, lr=1e-3)
+        tr = make_multimodal_trainer(model=model, train_dataloader=loader, eval_dataloader=[], optimizer=opt, log_dir=str(log_dir),
+                                     accelerator=acc, lr_scheduler=sch, avail_mod=["ap", "behavior"], config=load_config(),
+                                     modal_filter=dict(input=["ap", "behavior"], output=["ap", "behavior"]), mixed_training=True,
+                                     num_neurons=[n_ap])
+        return model, opt, sch, tr
+
+    # reference run: 6 steps
+    m0 = build_model(mc, n_ap, n_beh, seed=7); m0.engine_seed = 5
+    m0, opt0, sch0, tr0 = make(m0, batches(0, 6), tmp_path / "a")
+    random.seed(42); torch.manual_seed(99)
+    tr0.train_epoch(0)
+    want = {k: v.detach().clone() for k, v in m0.state_dict().items()}
+    # interrupted run: 3 steps, save, fresh objects, 3 more
+    m1 = build_model(mc, n_ap, n_beh, seed=7); m1.engine_seed = 5
+    (tmp_path / "b").mkdir()
+    m1, opt1, sch1, tr1 = make(m1, batches(0, 3), tmp_path / "b")
+    random.seed(42); torch.manual_seed(99)
+    tr1.train_epoch(0)
+    tr1.save_model(name="last", epoch=0)
+    del m1, opt1, sch1, tr1
+    random.seed(0); torch.manual_seed(0)                                  # scramble every host stream
+    ck = torch.load(tmp_path / "b" / "model_last.pt", weights_only=False)  # our own file (whole-module pickle, like the reference)
+    m2, opt2, sch2, tr2 = make(ck["model"], batches(3, 6), tmp_path / "b")
+    assert tr2.load_train_state(name="last") == 0
+    assert opt2._t == 3 and sch2.last_epoch == 3
+    tr2.train_epoch(1)
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, want[k]), k
+
+
+def test_optimizer_step_without_backward_is_a_noop():
+    """torch skips parameters whose .grad is None; the flat gradient buffer must not be applied a second time."""
+    model = build_model(tiny_config(), 12, 2, seed=7).cuda().train()
+    opt, sch = make_optimizer(model, 10)
+    out = model(to_dev(O.make_mod_dict(O.synth_batch(2, 8, 12, 2, seed=0), "encoding")))
+    out.loss.backward()
+    opt.step(); opt.zero_grad()
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    opt.step()                                   # no backward since zero_grad()
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k]), k
+    sd = opt.state_dict()
+    assert sd["fused"]["t"] == 1 and sd["fused"]["m"].abs().sum() > 0
