@@ -769,13 +769,111 @@ def fx_multisession_big():
                                             final_norm={k: float(v.double().norm()) for k, v in model.state_dict().items()}))
 
 
+EVAL_DRIVER_CASES = [
+    dict(mode="per_neuron", neurons=[0, 5, 9]),
+    dict(mode="forward_pred", held_out_list=[5, 6, 7]),
+    dict(mode="inter_region", target_regions=["CA1", "PO"], heldout_idxs=[0, 1]),
+    dict(mode="intra_region", target_regions=["CA1"], heldout_idxs=[1]),
+    dict(mode="modal_spike", held_out_list=[0, 1, 2, 3, 4, 5, 6, 7]),
+]
+
+
+def fx_eval_driver():
+    """The computational core of co_smoothing_eval (utils/eval_utils.py:93-757) on synthetic trials, built from the reference's own
+    pieces in the order the reference uses them: heldout_mask -> mod_dict (:157-193) -> model.eval() forward -> exp(preds) ->
+    bits_per_spike on the held-out slice, neuron by neuron (:200-203, :294-303, :399-408, :511-514).  Dataset access, PSTH
+    analysis and plotting (the rest of that function) are not part of the hot path and are not reproduced."""
+    import datasets
+    if not hasattr(datasets, "list_datasets"):
+        datasets.list_datasets = lambda *a, **k: []
+    _stub_wandb_torcheval()
+    import matplotlib
+    matplotlib.use("Agg")
+    from utils.eval_utils import bits_per_spike, heldout_mask
+    K_, T, N = 6, 8, 12
+    model = build_model(tiny_model_cfg(), N, 2, seed=21)
+    model.eval()
+    g = torch.Generator().manual_seed(77)
+    spikes = torch.poisson(torch.full((K_, T, N), 0.9), generator=g)
+    beh = torch.randn(K_, T, 2, generator=g)
+    regions = np.array(["CA1", "PO", "CA1", "LP", "PO", "CA1", "LP", "PO", "CA1", "DG", "PO", "LP"])
+    batch = dict(spikes_data=spikes, target=beh, time_attn_mask=torch.ones(K_, T, dtype=torch.int64),
+                 spikes_timestamps=torch.arange(T).unsqueeze(0).repeat(K_, 1))
+    arrs = {f"sd/{k}": npify(v) for k, v in model.state_dict().items()}
+    arrs.update(spikes=npify(spikes), behavior=npify(beh))
+    arrs["regions"] = np.frombuffer(json.dumps(regions.tolist()).encode(), dtype=np.uint8)
+
+    def run(mask_result, mask_mode):
+        md = {}
+        for mod in model.mod_to_indx.keys():
+            md[mod] = dict(inputs_modality=torch.tensor(model.mod_to_indx[mod]), targets_modality=torch.tensor(model.mod_to_indx[mod]),
+                           inputs_attn_mask=batch["time_attn_mask"], inputs_timestamp=batch["spikes_timestamps"],
+                           targets_timestamp=batch["spikes_timestamps"], eid="synthetic", num_neuron=N, masking_mode=None)
+            if mod == "ap":
+                md[mod].update(inputs=batch["spikes_data"].clone(), inputs_regions=np.asarray([regions] * K_),
+                               targets=batch["spikes_data"].clone(), eval_mask=mask_result["eval_mask"], mask_mode=mask_mode)
+            else:
+                md[mod].update(inputs=batch["target"].clone(), targets=batch["target"].clone(),
+                               eval_mask=torch.zeros_like(batch["target"]).to(torch.int64))
+        with torch.no_grad():
+            out = model(md)
+        return out.mod_targets["ap"][:, :, :N].numpy(), torch.exp(out.mod_preds["ap"][:, :, :N]).numpy(), float(out.loss)
+
+    def bps_list(gt, pr):
+        res = []
+        for n_i in range(gt.shape[2]):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                b = bits_per_spike(pr[:, :, [n_i]].astype(np.float64), gt[:, :, [n_i]].astype(np.float64))
+            res.append(float("nan") if np.isinf(b) else float(b))
+        return res
+
+    cases = []
+    for cid, c in enumerate(EVAL_DRIVER_CASES):
+        out = dict(c)
+        if c["mode"] == "per_neuron":
+            bl = []
+            for j, n_i in enumerate(c["neurons"]):
+                mr = heldout_mask(spikes.clone(), mode="manual", heldout_idxs=np.array([n_i]))
+                gt, pr, loss = run(mr, "neuron")
+                arrs[f"c{cid}/rates{j}"] = pr.astype(np.float32)
+                bl.append(bps_list(gt[:, :, [n_i]], pr[:, :, [n_i]])[0])
+            out["bps"] = bl
+        elif c["mode"] in ("forward_pred", "modal_spike"):
+            mr = heldout_mask(spikes.clone(), mode=c["mode"], heldout_idxs=np.array(c["held_out_list"]), target_regions=None, neuron_regions=regions)
+            gt, pr, loss = run(mr, "causal")
+            arrs[f"c{cid}/rates"] = pr.astype(np.float32)
+            t_i = c["held_out_list"]
+            out["bps"] = bps_list(gt[:, t_i], pr[:, t_i])
+        elif c["mode"] == "inter_region":
+            mr = heldout_mask(spikes.clone(), mode="inter_region", heldout_idxs=np.array(c["heldout_idxs"]), target_regions=c["target_regions"],
+                              neuron_regions=regions)
+            gt, pr, loss = run(mr, "inter-region")
+            arrs[f"c{cid}/rates"] = pr.astype(np.float32)
+            n_i = np.asarray(mr["heldout_idxs"])
+            out["heldout"] = n_i.tolist()
+            out["bps"] = bps_list(gt[:, :, n_i], pr[:, :, n_i])
+        else:
+            mr = heldout_mask(spikes.clone(), mode="intra_region", heldout_idxs=np.array(c["heldout_idxs"]), target_regions=c["target_regions"],
+                              neuron_regions=regions)
+            gt, pr, loss = run(mr, "intra-region")
+            arrs[f"c{cid}/rates"] = pr.astype(np.float32)
+            n_i = np.asarray(mr["heldout_idxs"])
+            out["heldout"] = n_i.tolist()
+            out["bps"] = bps_list(gt[:, :, n_i], pr[:, :, n_i])
+        out["loss"] = loss
+        cases.append(out)
+        print("   ", c["mode"], out["bps"][:4], loss)
+    arrs["meta"] = np.frombuffer(json.dumps(dict(cases=cases, K=K_, T=T, N=N, model_seed=21)).encode(), dtype=np.uint8)
+    save_npz("eval_driver.npz", **arrs)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     only = set(sys.argv[1:])
     for name, fn in [("init_order", fx_init_order), ("tiny_fwd_bwd", fx_tiny_fwd_bwd),
                      ("default_scalars", fx_default_scalars), ("masker_bits", fx_masker_bits),
                      ("mask_index_ops", fx_mask_index_ops), ("sched_adamw", fx_sched_adamw),
-                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("multisession_curve", fx_multisession_curve), ("eval_metrics", fx_eval_metrics), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate), ("masker_modes", fx_masker_modes),
+                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("multisession_curve", fx_multisession_curve), ("eval_metrics", fx_eval_metrics), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate), ("masker_modes", fx_masker_modes), ("eval_driver", fx_eval_driver),
                      ("h64_curve", fx_h64_curve), ("multisession_big", fx_multisession_big), ("loss_curve_1k_default", fx_loss_curve_1k_default)]:
         if only and name not in only:
             continue

@@ -108,3 +108,40 @@ def test_gpu_r2_series_and_metrics_list():
     assert trial_avg_r2(gt, pr) == pytest.approx(want, rel=1e-5)
     assert metrics_list(gt, pr, metrics=["r2"])["r2"] == pytest.approx(want, rel=1e-5)       # device path of the API mirror
     assert metrics_list(gt.cpu(), pr.cpu(), metrics=["r2"])["r2"] == pytest.approx(want, rel=1e-9)   # host path unchanged
+
+
+@pytest.mark.gpu
+def test_eval_driver_vs_reference_core_fixture():
+    """the forward-only evaluation driver (held-out mask -> engine eval plan -> exp -> per-neuron bits/spike on the
+    device) against the same pass assembled from the reference's own pieces (oracle/make_goldens.py:fx_eval_driver), every mode."""
+    import json
+    from helpers import build_model, tiny_config
+    from utils.eval_utils import co_smoothing_core
+    z, meta = load_npz("eval_driver.npz")
+    N = meta["N"]
+    model = build_model(tiny_config(), N, 2, seed=meta["model_seed"])
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")})
+    model.cuda().train()                                   # the driver switches to eval itself and restores the mode
+    regions = np.array(json.loads(bytes(z["regions"]).decode()))
+    K_, T = meta["K"], meta["T"]
+    batch = dict(spikes_data=torch.from_numpy(z["spikes"]).cuda(), target=torch.from_numpy(z["behavior"]).cuda(),
+                 time_attn_mask=torch.ones(K_, T, dtype=torch.int64, device="cuda"),
+                 spikes_timestamps=torch.arange(T, device="cuda").unsqueeze(0).repeat(K_, 1), eid=["synthetic"] * K_,
+                 neuron_regions=np.asarray([regions] * K_))
+    for cid, c in enumerate(meta["cases"]):
+        if c["mode"] == "per_neuron":
+            for j, n_i in enumerate(c["neurons"]):
+                res = co_smoothing_core(model, batch, "per_neuron", heldout_idxs=[n_i], region_list=regions)
+                np.testing.assert_allclose(res["rates"].cpu().numpy(), z[f"c{cid}/rates{j}"], rtol=2e-4, atol=1e-6)
+                assert res["bps"][0] == pytest.approx(c["bps"][j], rel=2e-3, abs=2e-4)
+            continue
+        hd = c.get("held_out_list", c.get("heldout_idxs"))
+        res = co_smoothing_core(model, batch, c["mode"], heldout_idxs=hd, target_regions=c.get("target_regions"), region_list=regions)
+        np.testing.assert_allclose(res["rates"].cpu().numpy(), z[f"c{cid}/rates"], rtol=2e-4, atol=1e-6, err_msg=c["mode"])
+        if "heldout" in c:
+            assert list(res["neurons"]) == c["heldout"]
+        np.testing.assert_allclose(res["bps"], np.asarray(c["bps"], dtype=np.float64), rtol=2e-3, atol=2e-4, equal_nan=True, err_msg=c["mode"])
+        if not np.isnan(c["loss"]):
+            assert res["loss"].item() == pytest.approx(c["loss"], rel=1e-4)
+        assert res["r2"].shape == (len(res["neurons"]),)
+    assert model.training
