@@ -22,7 +22,14 @@ def collate_ibl_trials(trials, target, max_time_length, max_space_length, pad_va
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("collate_ibl_trials runs mmfm_collate_csr on the GPU; there is no CPU path in this package")
-    data = np.concatenate([np.asarray(t["spikes_sparse_data"], dtype=np.uint8) for t in trials]) if B else np.zeros(0, np.uint8)
+    def counts(t):
+        """The IBL dataset stores the CSR values as ubyte; anything that would not survive the cast is refused, not wrapped."""
+        a = np.asarray(t["spikes_sparse_data"])
+        if a.size and (not np.issubdtype(a.dtype, np.integer) and np.any(a != np.floor(a)) or a.min() < 0 or a.max() > 255):
+            raise ValueError("collate_ibl_trials: spikes_sparse_data must hold integer counts in [0, 255] (uint8 CSR values, "
+                             f"as in the IBL datasets); got dtype {a.dtype}, range [{a.min()}, {a.max()}]")
+        return a.astype(np.uint8)
+    data = np.concatenate([counts(t) for t in trials]) if B else np.zeros(0, np.uint8)
     idx = np.concatenate([np.asarray(t["spikes_sparse_indices"], dtype=np.int32) for t in trials])
     ptr = np.concatenate([np.asarray(t["spikes_sparse_indptr"], dtype=np.int64) for t in trials])
     T_b = np.asarray([t["spikes_sparse_shape"][0] for t in trials], dtype=np.int32)

@@ -769,13 +769,16 @@ size_t bwd_lds_bytes(int Lq, int Lk, int dh) {
 template <typename K>
 int set_lds(K kern, size_t bytes) {
     static std::mutex mu;
-    static std::unordered_map<const void*, size_t> done;
+    static std::unordered_map<uint64_t, size_t> done;             // per (device, kernel)
     if (bytes <= 65536) return 0;
-    const void* key = reinterpret_cast<const void*>(kern);
+    const void* fn = reinterpret_cast<const void*>(kern);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t key = (uint64_t)(uintptr_t)fn ^ ((uint64_t)(dev + 1) << 56);
     std::lock_guard<std::mutex> g(mu);
     auto it = done.find(key);
     if (it != done.end() && it->second >= bytes) return 0;
-    hipError_t e = hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return mmfm_set_error((int)e, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
     done[key] = 160 * 1024;
     return 0;

@@ -1259,15 +1259,19 @@ size_t bwd_lds(int Lq, int Lk, int dh, int nw, int phase) {
     return images + (phase == 0 ? (size_t)2 * LqP * 4 : 0) + (size_t)nw * 32 * RS + LkP + std::max(Lq, Lk) + 64;
 }
 
+// the attribute belongs to the (device, kernel) pair: a process that drives several GPUs must opt in on each
 int opt_in_lds(const void* kern, size_t bytes) {
     static std::mutex mu;
-    static std::unordered_map<const void*, bool> done;
+    static std::unordered_map<uint64_t, bool> done;
     if (bytes <= 65536) return 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t key = (uint64_t)(uintptr_t)kern ^ ((uint64_t)(dev + 1) << 56);
     std::lock_guard<std::mutex> g(mu);
-    if (done.count(kern)) return 0;
+    if (done.count(key)) return 0;
     hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return mmfm_set_error((int)e, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
-    done[kern] = true;
+    done[key] = true;
     return 0;
 }
 
@@ -1321,7 +1325,14 @@ int mmfm_attn_bf16_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st
     if (backward) {
         const bool alb = d.lddo % 8 == 0 && d.lddq % 8 == 0 && d.lddk % 8 == 0 && d.lddv % 8 == 0 && (uintptr_t)d.d_o % 16 == 0 &&
                          (uintptr_t)d.dq % 16 == 0 && (uintptr_t)d.dk % 16 == 0 && (uintptr_t)d.dv % 16 == 0;
-        if (!alb) return -1000;
+        if (!alb) {
+            // the forward of this shape ran the bf16-MFMA kernel; the fp32-compute fallback lays its dropout hash out differently,
+            // so falling through would regenerate a DIFFERENT attention-dropout mask in the backward
+            if (d.drop_p.p > 0.f && d.drop_p.state != nullptr)
+                return mmfm_set_error(-1, "mmfm_attn_bwd(bf16): gradient tensors must be 16-byte aligned with leading dims %% 8 == 0 when "
+                                          "attention dropout is on (the fallback kernel family draws a different mask than the forward did)");
+            return -1000;
+        }
         if (bwd1_ok(d.Lq, d.Lk, d.dh)) {
             const size_t lds = bwd1_lds(d.Lq, d.Lk, d.dh);
 #define BWD1S(DHV)                                                                                                \

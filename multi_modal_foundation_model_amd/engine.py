@@ -721,7 +721,9 @@ class Engine:
             entries_fn()
             return
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread_local: with the DDP wrapper the previous bucket's all-reduce may still be running on RCCL's stream while the next
+        # backward segment is captured; the default (global) mode would treat that foreign-stream activity as a capture violation
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             entries_fn()
         plan["graphs"][tag] = graph
         graph.replay()

@@ -178,3 +178,12 @@ def test_multisession_big_gpu_vs_reference_fixture():
     np.testing.assert_allclose([x.item() for x in losses], g["loss"], rtol=1e-4)
     for k, v in model.state_dict().items():
         assert float(v.double().norm()) == pytest.approx(g["final_norm"][k], rel=1e-4, abs=1e-7), k
+
+
+def test_collate_refuses_counts_that_do_not_fit_uint8():
+    """The CSR values are ubyte upstream (IBL datasets); a silent wrap of 300 -> 44 would corrupt the spikes."""
+    from multi_modal_foundation_model_amd.collate import collate_ibl_trials
+    t = LO.synth_session_trials(5, 1, 4, seed=1, eid="s")[0]
+    bad = dict(t, spikes_sparse_data=[300] + list(t["spikes_sparse_data"])[1:])
+    with pytest.raises((ValueError, RuntimeError)):
+        collate_ibl_trials([bad], TARGET, 4, 5, -1.0, device="cuda" if __import__("torch").cuda.is_available() else "cpu")
