@@ -41,6 +41,7 @@ def parse():
                     help="batches start in pinned HOST memory and cross PCIe inside the timed region (the PCIe-inclusive rate quoted in "
                          "DESIGN.md; never the headline `value`, which is measured with inputs resident in HBM)")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the short fp32 / exact-masker / multi-session / config-5 legs")
     ap.add_argument("--cpu-steps", type=int, default=12, help="CPU-baseline steps at B=16 (~1 s each on 16 threads: a 10-15 s bounded sample)")
     return ap.parse_args()
 
@@ -140,6 +141,113 @@ def cpu_baseline(steps, B=16):
                 sample=f"{steps} train steps (fwd+bwd+AdamW) at B={B}, T=100, 668+2 channels, fp32 torch-CPU oracle, dropout as configured, "
                        f"{dt:.1f} s of CPU work (+ {n0} steps with dropout 0: {dt0:.1f} s)",
                 value_no_dropout=round(B * n0 / dt0, 3))
+
+
+def src_sha():
+    """Hash of the kernel sources: profiles/pmc_traffic.json records it, so a traffic figure measured on an older library is not
+    attached to this run's roofline line."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "multi_modal_foundation_model_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            with open(os.path.join(d, f), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def timed_leg(step, warm, steps):
+    for i in range(warm):
+        step(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(warm + i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def leg_trainer(dev, dtype, B, exact_masker, sessions=None, steps=8, warm=3):
+    """A short timed leg of the same trainer step with its own model: other precision (fp32 parity), the default masker stream,
+    or multi-session batches (BASELINE configs[2]: neurons right-padded with -1 to 668, one session per batch)."""
+    from torch.optim.lr_scheduler import OneCycleLR
+    from multi_modal_foundation_model_amd.builders import build_model, load_config
+    from multi_modal_foundation_model_amd.optim import make_optimizer
+    from multi_modal_foundation_model_amd.synthetic import synth_batch
+    from trainer.make import make_multimodal_trainer
+    import numpy as np
+    cfg = load_config()
+    model = build_model(cfg.model, 668, 2, seed=cfg.seed)
+    model.compute_dtype = dtype
+    model.engine_seed = 99
+    model.masker.token_mask_only = not exact_masker
+    model = model.to(dev).train()
+    opt = make_optimizer(model, lr=cfg.optimizer.lr, weight_decay=cfg.optimizer.wd, eps=cfg.optimizer.eps)
+    sch = OneCycleLR(optimizer=opt, total_steps=1000, max_lr=cfg.optimizer.lr, pct_start=cfg.optimizer.warmup_pct, div_factor=cfg.optimizer.div_factor)
+
+    class Acc:
+        device = dev
+    tr = make_multimodal_trainer(model=model, train_dataloader=[], eval_dataloader=[], optimizer=opt, log_dir="/tmp", accelerator=Acc(),
+                                 lr_scheduler=sch, avail_mod=["ap", "behavior"], config=cfg,
+                                 modal_filter=dict(input=["ap", "behavior"], output=["ap", "behavior"]), mixed_training=True, num_neurons=[668])
+    pool = []
+    n_pool = 4 if sessions is None else sessions
+    rng = np.random.default_rng(2024)
+    for i in range(n_pool):
+        b = synth_batch(B, 100, 668, 2, seed=7000 + i)
+        if sessions is not None:                          # session i has n_i neurons; the loader pads the rest with -1 (loader/base.py:407-425)
+            n_i = int(rng.integers(300, 669))
+            b["spikes_data"][:, :, n_i:] = -1.0
+            b["space_attn_mask"][:, n_i:] = 0
+            b["eid"] = [f"session{i}"] * B
+        pool.append({k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in b.items()})
+
+    def step(i):
+        tr._sample_modes()
+        out = tr._forward_model_outputs(dict(pool[i % len(pool)]), masking_mode=tr.masking_mode, training_mode=tr.training_mode)
+        out.loss.backward()
+        opt.step(); sch.step(); opt.zero_grad()
+        return out.loss
+    dt = timed_leg(step, warm, steps)
+    del model, opt, tr, pool
+    torch.cuda.empty_cache()
+    return dt
+
+
+def leg_config5(dev, B=256, steps=4, warm=2):
+    """BASELINE configs[4] as SURVEY.md §8d instantiates it: H=512, I=1024, dh=64, T=200, ap + behavior + lfp (L=600), bf16, dropout on."""
+    import numpy as np
+    from multi_modal_foundation_model_amd.builders import build_model_mods, make_optimizer, model_config
+    mods = [("ap", 668), ("behavior", 2), ("lfp", 128)]
+    model = build_model_mods(model_config(H=512, heads=8, inter=1024, max_F=200, n_modality=3), mods, seed=42)
+    model.loss_mod["lfp"] = "mse"
+    model.compute_dtype = "bf16"
+    model = model.to(dev).train()
+    opt, sch = make_optimizer(model, 1000)
+    g = torch.Generator().manual_seed(0)
+    T = 200
+    attn = torch.ones(B, T, dtype=torch.int64, device=dev)
+    ts = torch.arange(T, dtype=torch.int64)[None].repeat(B, 1).to(dev)
+    base = {}
+    for i, (name, n) in enumerate(mods):
+        x = (torch.poisson(torch.full((B, T, n), 0.3), generator=g) if name == "ap" else torch.randn(B, T, n, generator=g)).to(dev)
+        idx = torch.tensor(i, device=dev)
+        base[name] = dict(inputs_modality=idx, targets_modality=idx, inputs_attn_mask=attn, inputs_timestamp=ts, targets_timestamp=ts,
+                          masking_mode=None, inputs=x, targets=x,
+                          eval_mask=torch.full((1, 1, 1), 1 if name == "ap" else 0, dtype=torch.int64, device=dev).expand(B, T, n))
+        if name == "ap":
+            base[name]["inputs_regions"] = np.full((B, n), "XX")
+
+    def step(i):
+        out = model({m: dict(x) for m, x in base.items()})
+        out.loss.backward()
+        opt.step(); sch.step(); opt.zero_grad()
+        return out.loss
+    dt = timed_leg(step, warm, steps)
+    fl = 3 * flops_per_sample_fwd(model._engine.cfg, [n for _, n in mods], T) * B
+    del model, opt
+    torch.cuda.empty_cache()
+    return dt, fl
 
 
 def log(msg):
@@ -258,6 +366,8 @@ def main():
                    model_tflops_per_gpu=round(fl_step / (dt / a.steps) / 1e12, 2),
                    frac_of_mfma_peak_whole_step=round(fl_step / (dt / a.steps) / 1e12 / PEAK_TFLOPS[a.dtype], 4))
         res["inputs"] = "host (pinned), PCIe inside the timed region" if a.host_inputs else "resident in HBM"
+        res["masker_token_mask_only"] = True     # `value` skips the three dead [B,T,N] corruption draws of the embd path
+        res["fused_mask"] = eng._fused_mask(B * 200)
         log(f"{ms:.2f} ms/step, {value:.1f} samples/s")
         if not a.no_kernel_profile:
             log("per-kernel HIP-event profile")
@@ -277,15 +387,35 @@ def main():
             achieved = v[2] / (v[1] * 1e-3) / 1e12
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath):                 # only a PMC pass taken on THIS library (same kernel sources) is attached
                 with open(tpath) as f:
                     tj = json.load(f)
-                    if all(n in tj for n in FAM if n in agg):
-                        traffic = int(sum(tj[n] * agg[n][0] for n in FAM if n in agg) / max(1, v[0]))
+                if tj.get("src_sha") == src_sha() and all(n in tj for n in FAM if n in agg):
+                    traffic = int(sum(tj[n] * agg[n][0] for n in FAM if n in agg) / max(1, v[0]))
             res["roofline"] = dict(bound="mfma", kernel=k, launches_per_step=v[0], achieved=round(achieved, 2),
                                    peak=PEAK_TFLOPS[a.dtype], unit="TFLOP/s", frac=round(achieved / PEAK_TFLOPS[a.dtype], 4),
                                    traffic=traffic, avg_launch_ms=round(v[1] / v[0], 4),
                                    algorithmic_flops_per_launch=v[2] / v[0])
+        if world == 1 and not a.no_extra_legs:
+            try:
+                log("extra legs: exact masker stream, fp32 parity mode, multi-session, config 5")
+                dt = leg_trainer(dev, a.dtype, B, exact_masker=True, steps=6)
+                res["value_exact_masker"] = round(B / dt, 2)
+                Bf = min(B, 256)
+                dt = leg_trainer(dev, "fp32", Bf, exact_masker=False, steps=4, warm=2)
+                fl32 = 3 * flops_per_sample_fwd(eng.cfg, [n_ap, n_beh], T) * Bf
+                res["fp32_parity"] = dict(samples_per_sec=round(Bf / dt, 2), ms_per_step=round(dt * 1e3, 3), per_gpu_batch=Bf,
+                                          frac_of_fp32_mfma_peak=round(fl32 / dt / 1e12 / PEAK_TFLOPS["fp32"], 4))
+                dt = leg_trainer(dev, a.dtype, B, exact_masker=False, sessions=40, steps=8)
+                dt5, fl5 = leg_config5(dev, B=min(B, 256))
+                res["configs"] = dict(
+                    multi_session=dict(samples_per_sec=round(B / dt, 2), ms_per_step=round(dt * 1e3, 3), sessions=40,
+                                       note="BASELINE configs[2]: one session per batch, 300-668 neurons right-padded with -1 to 668"),
+                    config5=dict(samples_per_sec=round(min(B, 256) / dt5, 2), ms_per_step=round(dt5 * 1e3, 3), per_gpu_batch=min(B, 256),
+                                 model_tflops=round(fl5 / dt5 / 1e12, 1),
+                                 note="BASELINE configs[4] on one GPU: H=512, I=1024, dh=64, T=200, ap+behavior+lfp (L=600), bf16"))
+            except Exception as e:                      # the extra legs never take the headline down with them
+                res["extra_legs_error"] = repr(e)[:300]
         if world == 1 and not a.no_cpu_baseline:
             log("CPU baseline (oracle on host cores)")
             res["cpu_baseline"] = cpu_baseline(a.cpu_steps)
