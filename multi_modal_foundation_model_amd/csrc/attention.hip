@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mmfm_attn_desc d) {
     constexpr int SLD = DVL + 1;            // per-wave scratch stride
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kh = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int bh_ = attn_xcd_remap((int)blockIdx.x, (int)gridDim.x, d.flags);
+    const int b = bh_ / d.heads, h = bh_ % d.heads;
     const int Lq = d.Lq, Lk = d.Lk;
     const int LkP = (Lk + 31) & ~31;
     const int Lmx = max(Lq, Lk);
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mmfm_attn_desc d) {
                 const float p = ok[r] ? __expf(st[r] - m_use) : 0.f;
                 ps += p;
                 const int key = kt * 32 + mrow(r, kh);
-                pd[r] = dp.apply(p, ((uint64_t)blockIdx.x * Lq + (uint64_t)q) * Lk + (uint64_t)key);
+                pd[r] = dp.apply(p, ((uint64_t)bh_ * Lq + (uint64_t)q) * Lk + (uint64_t)key);
             }
             l_run = l_run * alpha + ps;
             m_run = m_new;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const mmfm_attn_desc d) {
         }
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         const float inv = 1.f / l_tot;                    // 0 allowed keys -> 0 * inf = NaN, like SDPA
-        if (kh == 0 && q < Lq) d.lse[((size_t)blockIdx.x) * Lq + q] = m_run + __logf(l_tot);
+        if (kh == 0 && q < Lq) d.lse[((size_t)bh_) * Lq + q] = m_run + __logf(l_tot);
         // ---- O^T (rows d, lane = query) -> scratch [q][d] -> coalesced rows, output dropout fused
         wave_lds_fence();
 #pragma unroll
@@ -200,7 +201,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const mmfm_attn_desc d) {
     constexpr int SLD = 33;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kh = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int bh_ = attn_xcd_remap((int)blockIdx.x, (int)gridDim.x, d.flags);
+    const int b = bh_ / d.heads, h = bh_ % d.heads;
     const int Lq = d.Lq, Lk = d.Lk;
     const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31;
     const int Lmx = max(Lq, Lk);
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const mmfm_attn_desc d) {
             p[2] = dout.apply(g.z, base + 2); p[3] = dout.apply(g.w, base + 3);
         }
     }
-    for (int i = t; i < LqP; i += 256) lse[i] = (i < Lq) ? d.lse[(size_t)blockIdx.x * Lq + i] : 0.f;
+    for (int i = t; i < LqP; i += 256) lse[i] = (i < Lq) ? d.lse[(size_t)bh_ * Lq + i] : 0.f;
     for (int i = t; i < LkP; i += 256) kpad[i] = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
     if (d.flags & MMFM_ATTN_SEP)
         for (int i = t; i < Lmx; i += 256) modl[i] = d.mod_id[i];
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const mmfm_attn_desc d) {
     MaskCtx mk{kpad, modl, modl, d.flags};
     float* sc = Sc + wave * 32 * SLD;
     const int nqt = LqP / 32, nkt = LkP / 32;
-    const uint64_t pbase = (uint64_t)blockIdx.x * Lq;
+    const uint64_t pbase = (uint64_t)bh_ * Lq;
 
     // ---------------- phase A: wave owns key tile kt -> dK, dV
     for (int kt = wave; kt < nkt; kt += 4) {
@@ -401,7 +403,8 @@ __global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const mmfm_attn_des
     constexpr int SLD = DVL + 1;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kh = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int bh_ = attn_xcd_remap((int)blockIdx.x, (int)gridDim.x, d.flags);
+    const int b = bh_ / d.heads, h = bh_ % d.heads;
     const int Lq = d.Lq, Lk = d.Lk;
     const int LkP = (Lk + 31) & ~31;
     const int Lmx = max(Lq, Lk);
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const mmfm_attn_des
                 const float p = ok[r] ? __expf(st[r] - m_use) : 0.f;
                 ps += p;
                 const int key = c0 + kt * 32 + mrow(r, kh);
-                pd[r] = dp.apply(p, ((uint64_t)blockIdx.x * Lq + (uint64_t)q) * Lk + (uint64_t)key);
+                pd[r] = dp.apply(p, ((uint64_t)bh_ * Lq + (uint64_t)q) * Lk + (uint64_t)key);
             }
             l_run = l_run * alpha + ps;
             m_run = m_new;
@@ -510,7 +513,7 @@ __global__ __launch_bounds__(256) void attn_fwd_tiled_kernel(const mmfm_attn_des
     if (!active) return;                               // no barrier below this point
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
-    if (kh == 0 && q < Lq) d.lse[((size_t)blockIdx.x) * Lq + q] = m_run + __logf(l_tot);
+    if (kh == 0 && q < Lq) d.lse[((size_t)bh_) * Lq + q] = m_run + __logf(l_tot);
     wave_lds_fence();
 #pragma unroll
     for (int i = 0; i < DT; ++i)
@@ -541,7 +544,8 @@ __global__ __launch_bounds__(256) void attn_bwd_tiled_kernel(const mmfm_attn_des
     constexpr int SLD = 33;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kh = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int bh_ = attn_xcd_remap((int)blockIdx.x, (int)gridDim.x, d.flags);
+    const int b = bh_ / d.heads, h = bh_ % d.heads;
     const int Lq = d.Lq, Lk = d.Lk;
     const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31;
     const int Lmx = max(Lq, Lk);
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(256) void attn_bwd_tiled_kernel(const mmfm_attn_des
             p[0] = dout.apply(g.x, base + 0); p[1] = dout.apply(g.y, base + 1);
             p[2] = dout.apply(g.z, base + 2); p[3] = dout.apply(g.w, base + 3);
         }
-        for (int i = t; i < rows; i += 256) lse[i] = (qw0 + i < Lq) ? d.lse[(size_t)blockIdx.x * Lq + qw0 + i] : 0.f;
+        for (int i = t; i < rows; i += 256) lse[i] = (qw0 + i < Lq) ? d.lse[(size_t)bh_ * Lq + qw0 + i] : 0.f;
     };
 
     for (int i = t; i < LkP; i += 256) kpad[i] = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
@@ -593,7 +597,7 @@ __global__ __launch_bounds__(256) void attn_bwd_tiled_kernel(const mmfm_attn_des
         for (int i = t; i < Lmx; i += 256) modl[i] = d.mod_id[i];
     MaskCtx mk{kpad, modl, modl, d.flags};
     float* sc = Sc + wave * 32 * SLD;
-    const uint64_t pbase = (uint64_t)blockIdx.x * Lq;
+    const uint64_t pbase = (uint64_t)bh_ * Lq;
     const int own0 = blockIdx.y * TCH;                 // first owned row (key for phase 0, query for phase 1)
     const int tl = wave;                               // owned tile, local to the window
 
@@ -862,7 +866,10 @@ static bool use_tiled(const mmfm_attn_desc& d) {
 
 extern "C" int mmfm_attn_fwd(const mmfm_attn_desc* dp, mmfm_stream stream) {
     MMFM_REQUIRE(dp, "mmfm_attn_fwd: null descriptor");
-    const mmfm_attn_desc d = *dp;
+    static const int no_remap = [] { const char* e = getenv("MMFM_ATTN_NO_REMAP"); return e ? atoi(e) : 0; }();
+    mmfm_attn_desc d_ = *dp;
+    d_.flags = (d_.flags & 0xff) | (no_remap ? 0x100 : 0);          // bit 8: plain workgroup order (common.h attn_xcd_remap)
+    const mmfm_attn_desc d = d_;
     if (int rc = check_common(d, "mmfm_attn_fwd")) return rc;
     if (d.dtype == MMFM_BF16) {          // bf16 MFMA kernel; shapes it does not take fall through to fp32 compute on bf16 storage
         const int rc = mmfm_attn_bf16_launch(d, false, (hipStream_t)stream);
@@ -884,7 +891,10 @@ extern "C" int mmfm_attn_fwd(const mmfm_attn_desc* dp, mmfm_stream stream) {
 
 extern "C" int mmfm_attn_bwd(const mmfm_attn_desc* dp, mmfm_stream stream) {
     MMFM_REQUIRE(dp, "mmfm_attn_bwd: null descriptor");
-    const mmfm_attn_desc d = *dp;
+    static const int no_remap = [] { const char* e = getenv("MMFM_ATTN_NO_REMAP"); return e ? atoi(e) : 0; }();
+    mmfm_attn_desc d_ = *dp;
+    d_.flags = (d_.flags & 0xff) | (no_remap ? 0x100 : 0);
+    const mmfm_attn_desc d = d_;
     if (int rc = check_common(d, "mmfm_attn_bwd")) return rc;
     MMFM_REQUIRE(d.d_o && d.dq && d.dk && d.dv, "mmfm_attn_bwd: null gradient tensor");
     const int hd = d.heads * d.dh;

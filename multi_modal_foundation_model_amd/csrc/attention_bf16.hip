@@ -183,7 +183,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kh = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int bh_ = attn_xcd_remap((int)blockIdx.x, (int)gridDim.x, d.flags);
+    const int b = bh_ / d.heads, h = bh_ % d.heads;
     const int Lq = d.Lq, Lk = d.Lk, LkP = (Lk + 31) & ~31, Lmx = max(Lq, Lk);
     char* Ks = smem;
     char* Vs = Ks + LkP * KRS;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
     for (int qt = wave; qt < nqt; qt += NW) {
         const int q0 = qt * 32, q = q0 + l31;
         // 32-bit pair index (wraps identically in the forward and both backward phases for very large batches)
-        const uint32_t pair_base = ((uint32_t)blockIdx.x * (uint32_t)Lq + (uint32_t)q) * (uint32_t)LkH;
+        const uint32_t pair_base = ((uint32_t)bh_ * (uint32_t)Lq + (uint32_t)q) * (uint32_t)LkH;
         bf16x8v qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -293,7 +294,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
         }
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         const float inv = 1.f / l_tot;
-        if (kh == 0 && q < Lq) d.lse[(size_t)blockIdx.x * Lq + q] = m_run * LN2 + __logf(l_tot);
+        if (kh == 0 && q < Lq) d.lse[(size_t)bh_ * Lq + q] = m_run * LN2 + __logf(l_tot);
         wave_lds_fence();
 #pragma unroll
         for (int i = 0; i < DT; ++i)
@@ -441,7 +442,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
     constexpr int C8 = DH / 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, kh = lane >> 5, l31 = lane & 31;
-    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int bh_ = attn_xcd_remap((int)blockIdx.x, (int)gridDim.x, d.flags);
+    const int b = bh_ / d.heads, h = bh_ % d.heads;
     const int Lq = d.Lq, Lk = d.Lk, LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31, Lmx = max(Lq, Lk);
     const int LA = PHASE == 0 ? LqP : LkP;            // rows of the two shared images
     char* As = smem;                                  // phase 0: Q        phase 1: K
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
         constexpr int PADC = RS / 16 - C8;
         for (int idx = t; idx < LqP * PADC; idx += NT)
             *reinterpret_cast<uint4*>(Bs + (idx / PADC) * RS + (C8 + idx % PADC) * 16) = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = t; i < LqP; i += NT) lse2[i] = (i < Lq) ? d.lse[(size_t)blockIdx.x * Lq + i] * LOG2E : 0.f;
+        for (int i = t; i < LqP; i += NT) lse2[i] = (i < Lq) ? d.lse[(size_t)bh_ * Lq + i] * LOG2E : 0.f;
     } else {
         load_head16<DH>(As, RS, RS / 16, kg, d.ldk, Lk, LkP, t, NT);
         load_head16<DH>(Bs, RS, RS / 16, vg, d.ldv, Lk, LkP, t, NT);
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
 
     const MaskCtx mk{kpad, modl, d.flags};
     const int nqt = LqP / 32, nkt = LkP / 32, LkH = (Lk + 1) >> 1;
-    const uint32_t pbase = (uint32_t)blockIdx.x * (uint32_t)Lq;
+    const uint32_t pbase = (uint32_t)bh_ * (uint32_t)Lq;
     const float c2 = d.scale * LOG2E;
     char* sct = Sc + wave * 32 * RS;
 
@@ -611,7 +613,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
             dofr[ks] = pack8(gd);
         }
         const float dq_ = dpart + __shfl_xor(dpart, 32);                 // delta[q]: the two half-waves hold the two halves of d
-        const float lq = (q < Lq) ? d.lse[(size_t)blockIdx.x * Lq + q] * LOG2E : 0.f;
+        const float lq = (q < Lq) ? d.lse[(size_t)bh_ * Lq + q] * LOG2E : 0.f;
         f32x16 s_next, dp_next;
         auto scoresB = [&](int kt) {
 #pragma unroll
@@ -675,7 +677,8 @@ __global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_
     // the wave index as a SCALAR: the two roles below then sit behind a uniform branch and share the register file
     // (a branch on a per-lane value keeps the other side's live values allocated: 165 instead of ~110 VGPRs)
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int bh_ = attn_xcd_remap((int)blockIdx.x, (int)gridDim.x, d.flags);
+    const int b = bh_ / d.heads, h = bh_ % d.heads;
     const int Lq = d.Lq, Lk = d.Lk, LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31, Lmx = max(Lq, Lk);
     char* As = smem;                                  // Q image
     char* Bs = As + LqP * RS;                         // dO image (output dropout applied)
@@ -722,7 +725,7 @@ __global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_
     constexpr int PADC = RS / 16 - C8;
     for (int idx = t; idx < LqP * PADC; idx += NT)
         *reinterpret_cast<uint4*>(Bs + (idx / PADC) * RS + (C8 + idx % PADC) * 16) = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = t; i < LqP; i += NT) lse2[i] = (i < Lq) ? d.lse[(size_t)blockIdx.x * Lq + i] * LOG2E : 0.f;
+    for (int i = t; i < LqP; i += NT) lse2[i] = (i < Lq) ? d.lse[(size_t)bh_ * Lq + i] * LOG2E : 0.f;
     int allk = 1;
     for (int i = t; i < LkP; i += NT) {
         const uint8_t v = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_
 
     const MaskCtx mk{kpad, modl, d.flags};
     const int nqt = LqP / 32, nkt = LkP / 32, LkH = (Lk + 1) >> 1;        // nkt <= CW (launcher)
-    const uint32_t pbase = (uint32_t)blockIdx.x * (uint32_t)Lq;
+    const uint32_t pbase = (uint32_t)bh_ * (uint32_t)Lq;
     const float c2 = d.scale * LOG2E;
 
     if (wave < CW) {
@@ -885,7 +888,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_tiled_kernel(const mmfm_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, kh = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int bh_ = attn_xcd_remap((int)blockIdx.x, (int)gridDim.x, d.flags);
+    const int b = bh_ / d.heads, h = bh_ % d.heads;
     const int Lq = d.Lq, Lk = d.Lk, LkP = (Lk + 31) & ~31, Lmx = max(Lq, Lk);
     char* Ks = smem;                                   // [TCH16][KRS]
     char* Vs = Ks + TCH16 * KRS;                       // [TCH16][VRS]
@@ -923,7 +927,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_tiled_kernel(const mmfm_
     const int qt = blockIdx.y * NW + wave;
     const bool active = qt < nqt;                      // inactive waves still take part in the chunk barriers
     const int q0 = qt * 32, q = q0 + l31;
-    const uint32_t pair_base = ((uint32_t)blockIdx.x * (uint32_t)Lq + (uint32_t)q) * (uint32_t)LkH;
+    const uint32_t pair_base = ((uint32_t)bh_ * (uint32_t)Lq + (uint32_t)q) * (uint32_t)LkH;
     bf16x8v qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -993,7 +997,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_tiled_kernel(const mmfm_
     if (!active) return;                               // no barrier below
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.f / l_tot;
-    if (kh == 0 && q < Lq) d.lse[(size_t)blockIdx.x * Lq + q] = m_run * LN2 + __logf(l_tot);
+    if (kh == 0 && q < Lq) d.lse[(size_t)bh_ * Lq + q] = m_run * LN2 + __logf(l_tot);
     wave_lds_fence();
 #pragma unroll
     for (int i = 0; i < DT; ++i)
@@ -1023,7 +1027,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, kh = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int b = blockIdx.x / d.heads, h = blockIdx.x % d.heads;
+    const int bh_ = attn_xcd_remap((int)blockIdx.x, (int)gridDim.x, d.flags);
+    const int b = bh_ / d.heads, h = bh_ % d.heads;
     const int Lq = d.Lq, Lk = d.Lk, LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31, Lmx = max(Lq, Lk);
     char* As = smem;                                  // phase 0: Q chunk     phase 1: K chunk     [TCH16][RS]
     char* Bs = As + TCH16 * RS;                       // phase 0: dO chunk    phase 1: V chunk
@@ -1059,7 +1064,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
 
     const MaskCtx mk{kpad, modl, d.flags};
     const int LkH = (Lk + 1) >> 1;
-    const uint32_t pbase = (uint32_t)blockIdx.x * (uint32_t)Lq;
+    const uint32_t pbase = (uint32_t)bh_ * (uint32_t)Lq;
     const float c2 = d.scale * LOG2E;
     char* sct = Sc + wave * 32 * RS;
 
@@ -1113,7 +1118,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
             constexpr int PADC = RS / 16 - C8;
             for (int idx = t; idx < rows * PADC; idx += NT)
                 *reinterpret_cast<uint4*>(Bs + (idx / PADC) * RS + (C8 + idx % PADC) * 16) = make_uint4(0u, 0u, 0u, 0u);
-            for (int i = t; i < rows; i += NT) lse2[i] = (c0 + i < Lq) ? d.lse[(size_t)blockIdx.x * Lq + c0 + i] * LOG2E : 0.f;
+            for (int i = t; i < rows; i += NT) lse2[i] = (c0 + i < Lq) ? d.lse[(size_t)bh_ * Lq + c0 + i] * LOG2E : 0.f;
             __syncthreads();
             if (!active) continue;
             const float* lse2g = lse2 - c0;            // indexed by the GLOBAL query
@@ -1188,7 +1193,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
             dofr[ks] = pack8(gd);
         }
         const float dq_ = dpart + __shfl_xor(dpart, 32);
-        const float lq = (active && q < Lq) ? d.lse[(size_t)blockIdx.x * Lq + q] * LOG2E : 0.f;
+        const float lq = (active && q < Lq) ? d.lse[(size_t)bh_ * Lq + q] * LOG2E : 0.f;
         const uint32_t pair_base = (pbase + (uint32_t)q) * (uint32_t)LkH;
         for (int c0 = 0; c0 < LkP; c0 += TCH16) {
             const int rows = min(TCH16, LkP - c0);

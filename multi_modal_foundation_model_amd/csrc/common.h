@@ -116,6 +116,18 @@ __device__ __forceinline__ Drop drop_init(mmfm_dropout d) {
     return r;
 }
 
+// ------------------------------------------------------------------ attention workgroup -> (batch, head)
+// One workgroup per (b, head) reads dh-wide slices of [.., heads*dh] rows: with dh = 32 a 128-B line holds TWO heads, and the
+// dispatcher deals consecutive workgroups round-robin over the 8 XCDs, so the heads of one sample landed on 8 different L2s and
+// every line was fetched from HBM once per head that touches it (PMC round 1: 631 MB fetched for 315 MB of q/k/v).  The bijective
+// XCD remap (cdna_hip_programming.md T1) gives every XCD a contiguous range of (b, head) ids: the heads of a sample run on one
+// XCD, back to back, and share its L2.  MMFM_ATTN_NO_REMAP bit (flags & 0x100) restores the plain order for A/B runs.
+__device__ __forceinline__ int attn_xcd_remap(int bid, int nwg, int flags) {
+    if (flags & 0x100) return bid;
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 // ------------------------------------------------------------------ activations
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
