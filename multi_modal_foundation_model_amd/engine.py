@@ -303,6 +303,8 @@ class Engine:
         c = self.cfg
         if self.dtype != "bf16" or c.hidden != 256 or c.inter != 512 or (R + 128) * 1024 * 2 >= 2 ** 31:
             return 0
+        if R < 16384 and "MMFM_FUSED" not in os.environ:
+            return 0             # a row-owner pass is 128 rows: below ~64 passes per launch the grid cannot fill 256 CUs (B=16: 5.04 vs 4.97 ms)
         return int(os.environ.get("MMFM_FUSED", "10")) & 15        # default: the group that measures faster end to end
 
     def _build_prep(self):
