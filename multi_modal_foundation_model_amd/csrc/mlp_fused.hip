@@ -11,11 +11,31 @@
 //   un-fused LN (2) + up (5) + down (4) = 11 x R x 256 x 2 B.
 // backward recomputes U_t / g_t from the saved x_hat (48 MFMAs per t instead of 32) and does the LayerNorm backward on the
 // accumulated d(x_hat) row in registers.
+#ifdef MMFM_STAMP
+#define RING_BARRIER_STAMP STAMP(7)
+#endif
 #include "rowchain.h"
 #include <stdlib.h>
 #include <algorithm>
 
 using namespace rowchain;
+
+#ifdef MMFM_STAMP
+// diagnostic build only (scripts/probe/build_stamp.sh): per-phase shader-cycle totals of wave 0 of every workgroup
+__device__ unsigned long long mmfm_probe_acc[16];
+#define STAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_a[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_a[i] += n_ - st_t; st_t = n_; } while (0)
+#define STAMP_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&mmfm_probe_acc[i_], st_a[i_]); } while (0)
+extern "C" int mmfm_probe_read(unsigned long long* host8, int reset) {
+    hipMemcpyFromSymbol(host8, HIP_SYMBOL(mmfm_probe_acc), 64);
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mmfm_probe_acc), z, 128); }
+    return 0;
+}
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH
+#endif
 
 namespace {
 
@@ -51,8 +71,9 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
     const Drop dr = drop_init(d.drop);
     const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4);
     const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2;
-    RING_DECL(NT);
-    RING_START(smem, my_passes * 32, src);
+    RINGD_DECL(NT);
+    RINGD_START(smem, my_passes * 32, src);
+    STAMP_DECL;
     for (int pi = 0; pi < my_passes; ++pi) {
         const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
         const uint32_t row = wrow0 + m;
@@ -65,14 +86,19 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) Y8[i] = zero16();
         const char* slot;
-        RING_STEP(src, slot);
+        STAMP(0);
+        RINGD_STEP_E(src, slot);
+        STAMP(1);
         f32x16 U = mma16<4>(slot, x, zero16(), m, h);                  // up(0)
+        asm volatile("" :: "v"(U[0]));
+        STAMP(2);
         for (int k = 0; k < 16; ++k) {
             const int tt = (k + rot) & 15;
             add_vec(U, lb_up, tt, h);
             f32x16 Un = zero16();
             if (k < 15) {                                               // up(k+1) interleaved with gelu(k), element by element
-                RING_STEP(src, slot);
+                RINGD_STEP_O(src, slot);
+                STAMP(1);
                 opnd wf[4];
 #pragma unroll
                 for (int part = 0; part < 4; ++part) {
@@ -99,18 +125,25 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
             }
             opnd g0, g1;
             acc_to_opnd(U, g0, g1);
-            RING_STEP(src, slot);                                       // down(k)
+            asm volatile("" :: "v"(Un[0]), "v"(g0[0]));
+            STAMP(3);
+            if (k < 15) RINGD_STEP_E(src, slot); else RINGD_STEP_O(src, slot);      // down(k): chunk 2k+2, the last one is chunk 31
+            STAMP(4);
 #pragma unroll
             for (int t2 = 0; t2 < 8; ++t2) {
                 Y8[t2] = mfma(wfragB(slot, t2, 0, m, h), g0, Y8[t2]);
                 Y8[t2] = mfma(wfragB(slot, t2, 1, m, h), g1, Y8[t2]);
             }
+            asm volatile("" :: "v"(Y8[7][0]));
+            STAMP(5);
             U = Un;
         }
+        Lines xl4[4];                                                   // all four residual line groups in flight at once
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) xl4[tp] = fetch_lines(X, wrow0, ldxb, 128u * tp, lane);
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) {
-            const Lines xl = fetch_lines(X, wrow0, ldxb, 128u * tp, lane);
-            stage_lines(stg, xl, lane);
+            stage_lines(stg, xl4[tp], lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int t2 = 2 * tp + j;
@@ -128,7 +161,9 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
             stage_tile(stg, 1, m, h, Y8[2 * tp + 1]);
             flush_lines<false>(stg, Y, wrow0, ldyb, 128u * tp, lane);
         }
+        STAMP(6);
     }
+    STAMP_FLUSH;
 }
 
 __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {

@@ -65,33 +65,54 @@ __device__ __forceinline__ void st4f(const GBuf& b, uint32_t off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, v), b.rs, (int)off, 0, 0);
 }
 
-// NT threads move one chunk (1024 16-B pieces) global -> registers -> LDS slot
+// NT threads move one chunk (1024 16-B pieces) global -> registers -> LDS slot.
+// At one wave per SIMD every vector instruction costs 4 cycles, and the first version spent ~1,100 cycles per ring step on
+// address arithmetic alone (measured: scripts/probe/mlp_stamp.py).  So: the loads go through ONE buffer descriptor per chunk
+// (wave-uniform base) with a per-thread byte offset that depends only on the chunk kind and row stride plus a SCALAR offset
+// per piece; the LDS addresses are two per-thread constants per kind (the XOR swizzles alternate between two values as the
+// piece index steps through the rows) plus immediates.
 template <int NT>
 __device__ __forceinline__ void stage_load(uint4 (&r)[1024 / NT], const WChunk& c, int t) {
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(c.base), 0, 0x7fffffff, 0x00020000);
+    const int ldb = c.ld * 2;
+    if (c.kind == 2) {                     // [256 rows][32 k]: piece p = t + NT q -> row p / 4 = t / 4 + (NT / 4) q, col t % 4
+        const int v0 = (t >> 2) * ldb + (t & 3) * 16;
 #pragma unroll
-    for (int q = 0; q < 1024 / NT; ++q) {
-        const int p = t + NT * q;
-        const int row = c.kind == 2 ? (p >> 2) : (p >> 5);
-        const int col = c.kind == 2 ? (p & 3) : (p & 31);
-        r[q] = *reinterpret_cast<const uint4*>(c.base + (size_t)row * c.ld + 8 * col);
+        for (int q = 0; q < 1024 / NT; ++q) r[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, v0, q * (NT / 4) * ldb, 0));
+    } else {                               // [32 rows][256 k]: row t / 32 + (NT / 32) q, col t % 32
+        const int v0 = (t >> 5) * ldb + (t & 31) * 16;
+#pragma unroll
+        for (int q = 0; q < 1024 / NT; ++q) r[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, v0, q * (NT / 32) * ldb, 0));
     }
 }
 template <int NT>
 __device__ __forceinline__ void stage_write(const uint4 (&r)[1024 / NT], int kind, char* slot, int t) {
+    constexpr int PP = 1024 / NT;
+    if (kind == 0) {                         // 512-B rows, 16-B chunk index XOR (row & 15): conflict-free ds_read_b128
+        // row = r0 + (NT/32) q with r0 = t / 32 < NT / 32 <= 16: (row & 15) = r0 ^ ((NT/32) q & 15) when NT/32 is 8 or 16
+        const int r0 = t >> 5, col = t & 31;
 #pragma unroll
-    for (int q = 0; q < 1024 / NT; ++q) {
-        const int p = t + NT * q;
-        if (kind == 0) {                     // 512-B rows, 16-B chunk index XOR (row & 15): conflict-free ds_read_b128
-            const int row = p >> 5, col = p & 31;
+        for (int q = 0; q < PP; ++q) {
+            const int row = r0 + (NT / 32) * q;
             *reinterpret_cast<uint4*>(slot + row * 512 + ((col ^ (row & 15)) << 4)) = r[q];
-        } else if (kind == 1) {              // PERM: 2x2 transpose of the 8-B units of each aligned 32-B pair
-            const int row = p >> 5, col = p & 31, c0 = col & ~1, e = col & 1;
+        }
+    } else if (kind == 1) {                  // PERM: 2x2 transpose of the 8-B units of each aligned 32-B pair
+        const int r0 = t >> 5, col = t & 31, c0 = col & ~1, e = col & 1;
+#pragma unroll
+        for (int q = 0; q < PP; ++q) {
+            const int row = r0 + (NT / 32) * q;
             *reinterpret_cast<uint2*>(slot + row * 512 + ((c0 ^ (row & 15)) << 4) + 8 * e) = make_uint2(r[q].x, r[q].y);
             *reinterpret_cast<uint2*>(slot + row * 512 + (((c0 + 1) ^ (row & 15)) << 4) + 8 * e) = make_uint2(r[q].z, r[q].w);
-        } else {                             // 64-B rows, chunk index XOR ((row >> 2) & 3), PERM
-            const int row = p >> 2, col = p & 3, c0 = col & 2, e = col & 1, sw = (row >> 2) & 3;
-            *reinterpret_cast<uint2*>(slot + row * 64 + ((c0 ^ sw) << 4) + 8 * e) = make_uint2(r[q].x, r[q].y);
-            *reinterpret_cast<uint2*>(slot + row * 64 + (((c0 + 1) ^ sw) << 4) + 8 * e) = make_uint2(r[q].z, r[q].w);
+        }
+    } else {                                 // 64-B rows, chunk index XOR ((row >> 2) & 3), PERM
+        // row = t / 4 + (NT/4) q: (row >> 2) & 3 = (t >> 4) & 3 for NT/4 a multiple of 16 -> ONE swizzle value per thread
+        const int r0 = t >> 2, col = t & 3, c0 = col & 2, e = col & 1, sw = (r0 >> 2) & 3;
+        char* a0 = slot + r0 * 64 + ((c0 ^ sw) << 4) + 8 * e;
+        char* a1 = slot + r0 * 64 + (((c0 + 1) ^ sw) << 4) + 8 * e;
+#pragma unroll
+        for (int q = 0; q < PP; ++q) {
+            *reinterpret_cast<uint2*>(a0 + q * (NT / 4) * 64) = make_uint2(r[q].x, r[q].y);
+            *reinterpret_cast<uint2*>(a1 + q * (NT / 4) * 64) = make_uint2(r[q].z, r[q].w);
         }
     }
 }
@@ -124,6 +145,43 @@ __device__ __forceinline__ void stage_write(const uint4 (&r)[1024 / NT], int kin
         ++ring_cc;                                                                           \
     } while (0)
 #define RING_STEP(SRC, SLOT) do { RING_SYNC_WRITE(SRC); RING_FETCH(SRC, SLOT); } while (0)
+
+// Prefetch distance TWO (measured with the stamped MLP kernel, scripts/probe/mlp_stamp.py: with distance one a chunk's L2 latency
+// - about one step long under load - sat in every step: 1,200-1,500 cycles per ring step, half of the kernel).  Two register
+// sets, selected by the PARITY of the chunk index at compile time (call sites alternate _E / _O, every pass has an even number
+// of chunks) so the code stays straight-line: at step cc chunk cc+1 (fetched two steps ago) is written to the free slot and
+// chunk cc+3 goes in flight into the set that just emptied.
+#define RINGD_DECL(NTV) uint4 ring_r0[1024 / (NTV)], ring_r1[1024 / (NTV)]; int ring_cc = 0, ring_last = 0; char* ring_smem = nullptr; constexpr int RING_NT = (NTV)
+#define RINGD_START(SMEM, TOTAL, SRC)                                                        \
+    do {                                                                                     \
+        ring_smem = (SMEM); ring_last = (TOTAL) - 1;                                         \
+        { const WChunk c0_ = SRC(0); stage_load<RING_NT>(ring_r0, c0_, t); stage_write<RING_NT>(ring_r0, c0_.kind, ring_smem, t); } \
+        { const WChunk c1_ = SRC(min(1, ring_last)); stage_load<RING_NT>(ring_r1, c1_, t); } \
+        { const WChunk c2_ = SRC(min(2, ring_last)); stage_load<RING_NT>(ring_r0, c2_, t); } \
+    } while (0)
+#ifndef RING_BARRIER_STAMP
+#define RING_BARRIER_STAMP
+#endif
+#define RINGD_SYNC_WRITE_(SRC, SET)                                                          \
+    do {                                                                                     \
+        __syncthreads();                                                                     \
+        RING_BARRIER_STAMP;                                                                  \
+        const WChunk cw_ = SRC(min(ring_cc + 1, ring_last));                                 \
+        stage_write<RING_NT>(SET, cw_.kind, ring_smem + ((ring_cc + 1) & 1) * CHUNK, t);     \
+    } while (0)
+#define RINGD_FETCH_(SRC, SLOT, SET)                                                         \
+    do {                                                                                     \
+        const WChunk cf_ = SRC(min(ring_cc + 3, ring_last));                                 \
+        stage_load<RING_NT>(SET, cf_, t);                                                    \
+        SLOT = ring_smem + (ring_cc & 1) * CHUNK;                                            \
+        ++ring_cc;                                                                           \
+    } while (0)
+#define RINGD_SYNC_WRITE_E(SRC) RINGD_SYNC_WRITE_(SRC, ring_r1)
+#define RINGD_SYNC_WRITE_O(SRC) RINGD_SYNC_WRITE_(SRC, ring_r0)
+#define RINGD_FETCH_E(SRC, SLOT) RINGD_FETCH_(SRC, SLOT, ring_r1)
+#define RINGD_FETCH_O(SRC, SLOT) RINGD_FETCH_(SRC, SLOT, ring_r0)
+#define RINGD_STEP_E(SRC, SLOT) do { RINGD_SYNC_WRITE_E(SRC); RINGD_FETCH_E(SRC, SLOT); } while (0)
+#define RINGD_STEP_O(SRC, SLOT) do { RINGD_SYNC_WRITE_O(SRC); RINGD_FETCH_O(SRC, SLOT); } while (0)
 
 // The same ring with 32 KB chunks made of two 16 KB sub-blocks (possibly of different matrices): twice the MFMAs per barrier.
 struct WChunk2 { WChunk s[2]; };
