@@ -116,11 +116,11 @@ __device__ __forceinline__ void epilogue_store(const mmfm_gemm_desc& d, const Dr
     typedef io<uint16_t> I16;
     if (d.bias) v += d.bias[n];
     if (d.pre_out) I16::st(reinterpret_cast<uint16_t*>(d.pre_out) + (size_t)m * d.ldc + n, v);
-    if (d.act == 1) v = gelu_erf(v);
+    if (d.act == 1) v = gelu_poly(v);
     else if (d.act == 2) v = softsign_f(v) * d.act_scale;
     if (d.gradmul_pre) {
         const float u = I16::ld(reinterpret_cast<const uint16_t*>(d.gradmul_pre) + (size_t)m * d.ldc + n);
-        v *= (d.act == 3) ? gelu_erf_grad(u) : softsign_grad(u) * d.act_scale;
+        v *= (d.act == 3) ? gelu_poly_grad(u) : softsign_grad(u) * d.act_scale;
     }
     v = dr.apply(v, (uint64_t)m * (uint64_t)d.N + (uint64_t)n);
     if (d.residual) v += I16::ld(reinterpret_cast<const uint16_t*>(d.residual) + (size_t)m * d.ldr + n);
@@ -180,8 +180,37 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
     if (vec_epi & 1) {
         float* stage = reinterpret_cast<float*>(smem);
         constexpr int SLDW = 132;
+        constexpr bool BF_OUT = sizeof(TO) == 2;
+        const bool bf_path = BF_OUT && !split;
+        const bool a16 = !(vec_epi & 2);
+        // every chunk of a thread has the same 8 columns (chunk & 15 == t & 15): bias is fetched once
+        const int col = (t & 15) * 8, n = n0 + col;
+        const bool n_ok = n < d.N, hi = n + 8 <= d.N;
+        float bs[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bs[e] = 0.f;
+        if (d.bias && n_ok && !split) {
+            const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n);
+            const float4 b1 = hi ? *reinterpret_cast<const float4*>(d.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
+        }
 #pragma unroll 1
         for (int half = 0; half < 2; ++half) {
+            // the half's epilogue operands (saved pre-activation, residual) are requested BEFORE the tile is staged: their
+            // latency runs under the two barriers and the LDS round trip instead of in front of every chunk (one 16-B load,
+            // use, next load ... was 4 exposed round trips per half: dg GEMM 193 us, down-projection 145 us at B = 1024)
+            uint4 gu[4], gr[4];
+            if (bf_path) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int m = m0 + half * 64 + ((t + 256 * c) >> 4);
+                    gu[c] = gr[c] = make_uint4(0u, 0u, 0u, 0u);
+                    if (m < d.M && n_ok) {
+                        if (d.gradmul_pre) gu[c] = ldg8(reinterpret_cast<const uint16_t*>(d.gradmul_pre) + (size_t)m * d.ldc + n, a16, hi, (vec_epi & 32768) != 0);
+                        if (d.residual) gr[c] = ldg8(reinterpret_cast<const uint16_t*>(d.residual) + (size_t)m * d.ldr + n, a16, hi, (vec_epi & 32768) != 0);
+                    }
+                }
+            }
             __syncthreads();
             if (wm == half) {
 #pragma unroll
@@ -195,20 +224,17 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
             __syncthreads();
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const int chunk = t + 256 * c, row = chunk >> 4, col = (chunk & 15) * 8;
-                const int m = m0 + half * 64 + row, n = n0 + col;
-                if (m >= d.M || n >= d.N) continue;          // chunks are all-in, all-out or (half mode) 4 columns in
-                const bool a16 = !(vec_epi & 2), hi = n + 8 <= d.N;
+                const int row = (t + 256 * c) >> 4;
+                const int m = m0 + half * 64 + row;
+                if (m >= d.M || !n_ok) continue;          // chunks are all-in, all-out or (half mode) 4 columns in
                 float v[8];
                 const float4 s0 = *reinterpret_cast<const float4*>(stage + row * SLDW + col);
                 const float4 s1 = *reinterpret_cast<const float4*>(stage + row * SLDW + col + 4);
                 v[0] = s0.x; v[1] = s0.y; v[2] = s0.z; v[3] = s0.w; v[4] = s1.x; v[5] = s1.y; v[6] = s1.z; v[7] = s1.w;
                 const size_t off = (size_t)m * d.ldc + n;
-                if (split || sizeof(TO) == 4) {
-                    if (!split && d.bias) {
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (e < 4 || hi) ? d.bias[n + e] : 0.f;
-                    }
+                for (int e = 0; e < 8; ++e) v[e] += bs[e];
+                if (split || !BF_OUT) {
                     float* dst = (split ? Cf : reinterpret_cast<float*>(d.C)) + off;
                     if (vec_epi & 16384) {
                         st_stream(reinterpret_cast<float4*>(dst), make_float4(v[0], v[1], v[2], v[3]));
@@ -219,33 +245,29 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
                     }
                     continue;
                 }
-                if (d.bias) {
-                    const float4 b0 = *reinterpret_cast<const float4*>(d.bias + n);
-                    const float4 b1 = hi ? *reinterpret_cast<const float4*>(d.bias + n + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                }
                 if (d.pre_out) stg8(reinterpret_cast<uint16_t*>(d.pre_out) + off, __builtin_bit_cast(uint4, pack8f(v)), a16, hi, (vec_epi & 8192) != 0);
-                if (d.act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-                } else if (d.act == 2) {
+                if (d.act == 1) gelu_n<8>(v);
+                else if (d.act == 2) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = softsign_f(v[e]) * d.act_scale;
                 }
                 if (d.gradmul_pre) {
                     float u[8];
-                    unpack8(ldg8(reinterpret_cast<const uint16_t*>(d.gradmul_pre) + off, a16, hi, (vec_epi & 32768) != 0), u);
+                    unpack8(gu[c], u);
+                    if (d.act == 3) mul_gelu_grad_n<8>(v, u);
+                    else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] *= (d.act == 3) ? gelu_erf_grad(u[e]) : softsign_grad(u[e]) * d.act_scale;
+                        for (int e = 0; e < 8; ++e) v[e] *= softsign_grad(u[e]) * d.act_scale;
+                    }
                 }
                 if (dr.on()) {
                     const uint64_t base = (uint64_t)m * (uint64_t)d.N + (uint64_t)n;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = dr.keep(base + e) ? v[e] * dr.scale : 0.f;
+                    for (int e = 0; e < 8; e += 2) dr.apply2(v[e], v[e + 1], base + e);      // n and N are even here, so base is
                 }
                 if (d.residual) {
                     float u[8];
-                    unpack8(ldg8(reinterpret_cast<const uint16_t*>(d.residual) + (size_t)m * d.ldr + n, a16, hi, (vec_epi & 32768) != 0), u);
+                    unpack8(gr[c], u);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += u[e];
                 }

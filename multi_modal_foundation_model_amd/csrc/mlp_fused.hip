@@ -107,7 +107,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         Un = mfma(wf[s], x[4 * part + s], Un);
-                        U[4 * part + s] = gelu_fast(U[4 * part + s]);
+                        if (s & 1) gelu_pair(U, 4 * part + s - 1);
                     }
                 }
                 // hipcc clusters the 16 MFMAs and runs the GELU behind them; pin the interleave: per MFMA one LDS read, the
@@ -120,8 +120,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
                     __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
                 }
             } else {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) U[i] = gelu_fast(U[i]);
+                gelu16(U);
             }
             opnd g0, g1;
             acc_to_opnd(U, g0, g1);
@@ -149,9 +148,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
                 const int t2 = 2 * tp + j;
                 add_vec(Y8[t2], lb_dn, t2, h);
                 if (dr.on()) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        Y8[t2][i] = dr.keep((uint64_t)row * 256u + (uint64_t)feat(t2, i, h)) ? Y8[t2][i] * dr.scale : 0.f;
+                    drop16(dr, Y8[t2], row, t2, h);
                 }
                 const f32x16 r = unstage_tile(stg, j, m, h);
 #pragma unroll
@@ -206,9 +203,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 float f[8]; unpack8f(t1[s], f);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    f[j] = dr.keep((uint64_t)row * 256u + (uint64_t)(16 * s + 8 * h + j)) ? f[j] * dr.scale : 0.f;
+                drop8(dr, f, row, 16 * s + 8 * h);
                 t1[s] = pack8o(f);
             }
         }
@@ -225,8 +220,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
             RING_STEP(src, slot);
             f32x16 DG = mma16(slot, t1, zero16(), m, h);
             f32x16 Gt;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { Gt[i] = gelu_fast(U[i]); DG[i] *= gelu_grad_fast(U[i]); }
+            gelu_fwd_bwd16(U, Gt, DG);
             opnd d0, d1;
             acc_to_opnd(DG, d0, d1);
             RING_SYNC_WRITE(src);
@@ -348,8 +342,7 @@ __global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
             RING2_STEP(src, slot);
             f32x16 U = mma16<4>(slot + role * CHUNK, x, zero16(), m, h);
             add_vec(U, lb_up, 2 * u + role, h);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) U[i] = gelu_fast(U[i]);
+            gelu16(U);
             opnd g0, g1;
             acc_to_opnd(U, g0, g1);
             *reinterpret_cast<uint4*>(exch + role * 2048 + lane * 16) = as_u4(g0);
@@ -378,9 +371,7 @@ __global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
                 const int t2 = 2 * lp + j;
                 add_vec(Yh[2 * q + j], lb_dn, t2, h);
                 if (dr.on()) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        Yh[2 * q + j][i] = dr.keep((uint64_t)row * 256u + (uint64_t)feat(t2, i, h)) ? Yh[2 * q + j][i] * dr.scale : 0.f;
+                    drop16(dr, Yh[2 * q + j], row, t2, h);
                 }
                 const f32x16 r = unstage_tile(stg, j, m, h);
 #pragma unroll
@@ -440,9 +431,7 @@ __global__ __launch_bounds__(NT8) void mlp_bwd8_kernel(const mmfm_mlp_desc d) {
 #pragma unroll
                 for (int s = 0; s < 16; ++s) {
                     float f[8]; unpack8f(x[s], f);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        f[j] = dr.keep((uint64_t)row * 256u + (uint64_t)(16 * s + 8 * h + j)) ? f[j] * dr.scale : 0.f;
+                    drop8(dr, f, row, 16 * s + 8 * h);
                     x[s] = pack8o(f);
                 }
             }
@@ -465,7 +454,11 @@ __global__ __launch_bounds__(NT8) void mlp_bwd8_kernel(const mmfm_mlp_desc d) {
                     add_vec(A2[j], lb_up, 2 * u + j, h);
                     uint32_t gp[8];
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) gp[i] = pack2(gelu_grad_fast(A2[j][2 * i]), gelu_grad_fast(A2[j][2 * i + 1]));
+                    for (int i = 0; i < 8; ++i) {
+                        mmfm_f32x2 a; a.x = A2[j][2 * i]; a.y = A2[j][2 * i + 1];
+                        a = gelu_grad2(a);
+                        gp[i] = pack2(a.x, a.y);
+                    }
                     *reinterpret_cast<uint4*>(exch + (2 * j) * 1024 + lane * 16) = make_uint4(gp[0], gp[1], gp[2], gp[3]);
                     *reinterpret_cast<uint4*>(exch + (2 * j + 1) * 1024 + lane * 16) = make_uint4(gp[4], gp[5], gp[6], gp[7]);
                 }
@@ -483,10 +476,8 @@ __global__ __launch_bounds__(NT8) void mlp_bwd8_kernel(const mmfm_mlp_desc d) {
                     acc_to_opnd(A2[j], du[2 * j], du[2 * j + 1]);
                 }
             } else {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) A2[j][i] = gelu_fast(A2[j][i]);
+                gelu16(A2[0]);
+                gelu16(A2[1]);
             }
             // both roles: their tile pair (A: g, B: du) leaves as whole lines of the [R][512] tensor
             stage_tile(stg, 0, m, h, A2[0]);

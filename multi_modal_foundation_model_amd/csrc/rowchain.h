@@ -415,24 +415,49 @@ __device__ __forceinline__ float ln_rows(opnd (&x)[16], float eps) {
     return rs;
 }
 
-// ---- cheap exact-enough GELU for bf16 storage: erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far below the
-// 2^-9 relative step of the bf16 value it feeds)
-__device__ __forceinline__ float erf_as(float x) {
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    p *= t;
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-    const float r = fmaf(-p, e, 1.f);
-    return copysignf(r, x);
+// ---- dropout on an accumulator tile of output tile t2 (element counter row*256 + feature; registers i, i+1 with i even are
+// neighbouring features: one hash per pair)
+__device__ __forceinline__ void drop16(const Drop& dr, f32x16& v, uint32_t row, int t2, int h) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        const uint32_t hh = dr.hash((row * 256u + (uint32_t)feat(t2, i, h)) >> 1);      // tensors here are < 2^31 bytes
+        v[i] = dr.lo(hh) ? v[i] * dr.scale : 0.f;
+        v[i + 1] = dr.hi(hh) ? v[i + 1] * dr.scale : 0.f;
+    }
 }
-__device__ __forceinline__ float gelu_fast(float x) { return 0.5f * x * (1.f + erf_as(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad_fast(float x) {
-    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);      // exp(-x^2/2)
-    return 0.5f * (1.f + erf_as(x * 0.70710678118654752f)) + x * 0.39894228040143268f * e;
+// ... and on 8 consecutive features k0 .. k0+7 (k0 a multiple of 8) of `row`
+__device__ __forceinline__ void drop8(const Drop& dr, float (&f)[8], uint32_t row, int k0) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const uint32_t hh = dr.hash((row * 256u + (uint32_t)(k0 + j)) >> 1);
+        f[j] = dr.lo(hh) ? f[j] * dr.scale : 0.f;
+        f[j + 1] = dr.hi(hh) ? f[j + 1] * dr.scale : 0.f;
+    }
+}
+
+// ---- GELU on accumulator tiles: the packed polynomial of common.h (phi2), two registers per instruction
+__device__ __forceinline__ void gelu16(f32x16& U) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        mmfm_f32x2 a; a.x = U[i]; a.y = U[i + 1];
+        a = gelu2(a);
+        U[i] = a.x; U[i + 1] = a.y;
+    }
+}
+__device__ __forceinline__ void gelu_pair(f32x16& U, int i) {                  // registers i, i + 1 (i even)
+    mmfm_f32x2 a; a.x = U[i]; a.y = U[i + 1];
+    a = gelu2(a);
+    U[i] = a.x; U[i + 1] = a.y;
+}
+// G = gelu(U), D *= gelu'(U)
+__device__ __forceinline__ void gelu_fwd_bwd16(const f32x16& U, f32x16& G, f32x16& D) {
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        mmfm_f32x2 a, g, dg; a.x = U[i]; a.y = U[i + 1];
+        gelu_both2(a, g, dg);
+        G[i] = g.x; G[i + 1] = g.y;
+        D[i] *= dg.x; D[i + 1] *= dg.y;
+    }
 }
 
 // 16 MFMAs of one [32][256] chunk against 16 operands, weight operands fetched 8 at a time (the ds_read latency of a
