@@ -62,22 +62,26 @@ struct MaskCtx {
     }
 };
 
-// Dropout on the probabilities, two decisions per hash: element (q, key) uses the low (even key) or high
-// (odd key) 16 bits of hash(pair index), pair index = (bh*Lq + q) * ceil(Lk/2) + key/2 (mod 2^32).  Forward and both
-// backward phases evaluate the same function, so no mask is stored.
+// Dropout on the probabilities.  One hash decides a PAIR of keys (even key: low 16 bits, odd key: high 16 bits, each against
+// the top 16 bits of the threshold).  The hash is two-level: a full-strength 2 x 32-bit ROW key per (batch, head, query)
+// - computed once per query tile (forward, dQ phase: lane = query) or once per workgroup into an LDS table (dK/dV phase:
+// lane = key) - and a 7-instruction xorshift / 24-bit-multiply mix of (pair index ^ key A, key B) per pair.  Forward and
+// both backward phases evaluate the same function, so no mask is stored.  v_mul_u32_u24 issues at the full VALU rate,
+// v_mul_lo_u32 at a quarter of it, and a step draws ~10^9 of these decisions: the round-1 version (11 instructions per pair
+// on a linear pair index, plus a 32-bit multiply to form that index in the dK/dV phase) was ~40 % of the forward tile's VALU work.
 struct Drop16 {
     uint32_t k0, k1, t16;
     float scale;
     bool on;
-    // xorshift / 24-bit-multiply mixer: v_mul_u32_u24 issues at the full VALU rate, v_mul_lo_u32 at a quarter
-    // of it, and the probabilities need ~10^9 decisions per step.  Each xorshift folds the bits the next 24-bit
-    // multiply would drop back into its low 24 bits.
-    __device__ __forceinline__ uint32_t hash(uint32_t pidx) const {
-        uint32_t h = pidx ^ k0;
-        h ^= h >> 16;
-        h = __umul24(h, 0x7FEB35u) + k1;
+    __device__ __forceinline__ void rowkeys(uint32_t rowid, uint32_t& ka, uint32_t& kb) const {       // rowid = bh * Lq + q
+        ka = mix32(rowid ^ k0);
+        kb = mix32((rowid + 0x9E3779B9u) ^ k1);
+    }
+    // jx = (key >> 1) ^ ka
+    __device__ __forceinline__ uint32_t hash(uint32_t jx, uint32_t kb) const {
+        uint32_t h = __umul24(jx, 0x7FEB35u) + kb;
         h ^= h >> 13;
-        h = __umul24(h, 0x46CA6Bu) ^ (h >> 9);
+        h = __umul24(h, 0x46CA6Bu);
         h ^= h >> 16;
         return h;
     }
@@ -114,7 +118,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // the last key tile of a 200-token head has one (keys 192..199), so three quarters of its element-wise work is skipped.
 template <bool FULL, bool DROP>
 __device__ __forceinline__ bool fwd_tile(const f32x16& st, float c2, float& m_run, float& l_run, float& alpha, float (&pd)[16], int q,
-                                         int Lq, int Lk, int kt, int kh, const MaskCtx& mk, const Drop16& dp, uint32_t pair_base, int G) {
+                                         int Lq, int Lk, int kt, int kh, const MaskCtx& mk, const Drop16& dp, uint32_t ka, uint32_t kb, int G) {
     uint32_t okm = 0xffffu;
     float mx = -INFINITY;
     if (FULL) {
@@ -142,6 +146,9 @@ __device__ __forceinline__ bool fwd_tile(const f32x16& st, float c2, float& m_ru
     const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
     alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(m_run - m_use);
     float ps = 0.f;
+    // pair index of register r: (kt*32 + mrow(r, kh)) >> 1 = (16 kt + 2 kh) | (mrow(r, 0) >> 1): disjoint bits, so the tile part is
+    // XOR-ed into the row key once and every pair costs one XOR with a literal
+    const uint32_t jbase = (uint32_t)(16 * kt + 2 * kh) ^ ka;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (g < G) {
@@ -155,9 +162,9 @@ __device__ __forceinline__ bool fwd_tile(const f32x16& st, float c2, float& m_ru
                 }
                 ps += p0 + p1;
                 if (DROP) {
-                    const uint32_t hsh = dp.hash(pair_base + (uint32_t)((kt * 32 + mrow(r, kh)) >> 1));
-                    p0 = (hsh & 0xffffu) >= dp.t16 ? p0 * dp.scale : 0.f;
-                    p1 = (hsh >> 16) >= dp.t16 ? p1 * dp.scale : 0.f;
+                    const uint32_t hsh = dp.hash(jbase ^ (uint32_t)(mrow(r, 0) >> 1), kb);
+                    p0 = (hsh & 0xffffu) >= dp.t16 ? p0 : 0.f;       // the 1/(1-p) factor rides on the final normalisation
+                    p1 = (hsh >> 16) >= dp.t16 ? p1 : 0.f;
                 }
                 pd[r] = p0;
                 pd[r + 1] = p1;
@@ -221,13 +228,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
     const Drop16 dp = drop16_init(d.drop_p);
     const Drop dout = drop_init(d.drop_o);
     float* sc = Sc + wave * 32 * SLD;
-    const int nqt = (Lq + 31) / 32, nkt = LkP / 32, LkH = (Lk + 1) >> 1;
+    const int nqt = (Lq + 31) / 32, nkt = LkP / 32;
     const float c2 = d.scale * LOG2E;
 
     for (int qt = wave; qt < nqt; qt += NW) {
         const int q0 = qt * 32, q = q0 + l31;
-        // 32-bit pair index (wraps identically in the forward and both backward phases for very large batches)
-        const uint32_t pair_base = ((uint32_t)bh_ * (uint32_t)Lq + (uint32_t)q) * (uint32_t)LkH;
+        uint32_t ka, kb;                                   // dropout row keys of this lane's query
+        dp.rowkeys((uint32_t)bh_ * (uint32_t)Lq + (uint32_t)q, ka, kb);
         bf16x8v qf[KS];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -262,11 +269,11 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
             // zero-padded rows give finite scores) - the softmax of a query is lane-local.
             const int nk = min(32, Lk - kt * 32), G = (nk + 7) >> 3;
             if (nomask && (nk & 7) == 0)
-                live = dp.on ? fwd_tile<true, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G)
-                             : fwd_tile<true, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G);
+                live = dp.on ? fwd_tile<true, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, ka, kb, G)
+                             : fwd_tile<true, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, ka, kb, G);
             else
-                live = dp.on ? fwd_tile<false, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G)
-                             : fwd_tile<false, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G);
+                live = dp.on ? fwd_tile<false, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, ka, kb, G)
+                             : fwd_tile<false, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, ka, kb, G);
             if (!live) return;
             const bf16x8v pf0 = pack8(pd), pf1 = pack8(pd + 8);
             const bool rescale = !__all(alpha == 1.f);
@@ -293,7 +300,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
             }
         }
         const float l_tot = l_run + __shfl_xor(l_run, 32);
-        const float inv = 1.f / l_tot;
+        const float inv = dp.scale / l_tot;
         if (kh == 0 && q < Lq) d.lse[(size_t)bh_ * Lq + q] = m_run * LN2 + __logf(l_tot);
         wave_lds_fence();
 #pragma unroll
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 2) void attn_fwd_bf16_kernel
 template <bool FULL, bool DROP>
 __device__ __forceinline__ void bwdA_half(const f32x16& s, const f32x16& dpv, int s2, float (&pd)[8], float (&ds)[8], float c2, float scale,
                                           const float* lse2, const float* dlt, int qt, int key, int kh, int Lq, int Lk, const MaskCtx& mk,
-                                          const Drop16& dp, uint32_t pbase, int LkH, int G) {
+                                          const Drop16& dp, const uint2* rkey, int G) {
     // One hash decides a PAIR of keys (even key: low 16 bits, odd key: high 16 bits).  Here the lane is the key, so the two
     // keys of a pair sit in neighbouring lanes and would both evaluate the same hash: instead the even lane hashes the
     // half-tile's first four queries, the odd lane its last four, and a quad-permute DPP move swaps them (12 -> 7.5 VALU
@@ -337,7 +344,8 @@ __device__ __forceinline__ void bwdA_half(const f32x16& s, const f32x16& dpv, in
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int qmine = qt * 32 + e + 8 * (2 * s2 + par) + 4 * kh;          // = mrow(8*s2 + e + 4*par, kh)
-                const uint32_t mine = dp.hash((pbase + (uint32_t)qmine) * (uint32_t)LkH + (uint32_t)(key >> 1));
+                const uint2 kk = rkey[qmine];                                           // row keys of query qmine (LDS table)
+                const uint32_t mine = dp.hash((uint32_t)(key >> 1) ^ kk.x, kk.y);
                 const uint32_t other = (uint32_t)__builtin_amdgcn_mov_dpp((int)mine, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
                 hq[e] = par ? other : mine;          // query e      (hashed by the even lane)
                 hq[e + 4] = par ? mine : other;      // query e + 4  (hashed by the odd lane)
@@ -345,7 +353,8 @@ __device__ __forceinline__ void bwdA_half(const f32x16& s, const f32x16& dpv, in
         } else {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                hq[e] = dp.hash((pbase + (uint32_t)(qt * 32 + e + 16 * s2 + 4 * kh)) * (uint32_t)LkH + (uint32_t)(key >> 1));
+                const uint2 kk = rkey[qt * 32 + e + 16 * s2 + 4 * kh];
+                hq[e] = dp.hash((uint32_t)(key >> 1) ^ kk.x, kk.y);
                 hq[e + 4] = 0u;
             }
         }
@@ -366,18 +375,19 @@ __device__ __forceinline__ void bwdA_half(const f32x16& s, const f32x16& dpv, in
         if (DROP) {
             const uint32_t hsh = hq[e];
             const bool keep = ((key & 1) ? (hsh >> 16) : (hsh & 0xffffu)) >= dp.t16;
-            pdrop = keep ? p * dp.scale : 0.f;
-            g = keep ? g * dp.scale : 0.f;
+            pdrop = keep ? p : 0.f;
+            g = keep ? g : 0.f;
         }
         pd[e] = pdrop;
-        ds[e] = p * (g - dlt[q]) * scale;
+        ds[e] = p * (g - dlt[q]);
     }
 }
 
 // Phase B, one tile (lane = query, accumulator rows = keys): dS^T.
 template <bool FULL, bool DROP>
 __device__ __forceinline__ void bwdB_tile(const f32x16& s, const f32x16& dpv, float (&ds)[16], float c2, float scale, float lq, float dq_,
-                                          int q, int kt, int kh, int Lq, int Lk, const MaskCtx& mk, const Drop16& dp, uint32_t pair_base) {
+                                          int q, int kt, int kh, int Lq, int Lk, const MaskCtx& mk, const Drop16& dp, uint32_t ka, uint32_t kb) {
+    const uint32_t jbase = (uint32_t)(16 * kt + 2 * kh) ^ ka;         // see fwd_tile
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
         const int key = kt * 32 + mrow(r, kh);
@@ -389,12 +399,12 @@ __device__ __forceinline__ void bwdB_tile(const f32x16& s, const f32x16& dpv, fl
         }
         float g0 = dpv[r], g1 = dpv[r + 1];
         if (DROP) {
-            const uint32_t hsh = dp.hash(pair_base + (uint32_t)(key >> 1));
-            g0 = (hsh & 0xffffu) >= dp.t16 ? g0 * dp.scale : 0.f;
-            g1 = (hsh >> 16) >= dp.t16 ? g1 * dp.scale : 0.f;
+            const uint32_t hsh = dp.hash(jbase ^ (uint32_t)(mrow(r, 0) >> 1), kb);
+            g0 = (hsh & 0xffffu) >= dp.t16 ? g0 : 0.f;
+            g1 = (hsh >> 16) >= dp.t16 ? g1 : 0.f;
         }
-        ds[r] = p0 * (g0 - dq_) * scale;
-        ds[r + 1] = p1 * (g1 - dq_) * scale;
+        ds[r] = p0 * (g0 - dq_);
+        ds[r + 1] = p1 * (g1 - dq_);
     }
 }
 
@@ -402,7 +412,7 @@ __device__ __forceinline__ void bwdB_tile(const f32x16& s, const f32x16& dpv, fl
 // already consumed 32-row tile of an LDS image (RS-byte rows), then streamed to global as 16-B row chunks.
 template <int DH, int DT>
 __device__ __forceinline__ void store_tile_T(char* tile, int RS, const f32x16 (&acc)[DT], uint16_t* outg, int ld, int row0, int nrows_total,
-                                             int lane) {
+                                             int lane, float osc) {
     const int l31 = lane & 31, kh = lane >> 5;
     wave_lds_fence();
 #pragma unroll
@@ -413,8 +423,8 @@ __device__ __forceinline__ void store_tile_T(char* tile, int RS, const f32x16 (&
             if (dcol < DH) {
                 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
                 bf16x4v v;
-                v[0] = (__bf16)acc[i][4 * g + 0]; v[1] = (__bf16)acc[i][4 * g + 1];
-                v[2] = (__bf16)acc[i][4 * g + 2]; v[3] = (__bf16)acc[i][4 * g + 3];
+                v[0] = (__bf16)(acc[i][4 * g + 0] * osc); v[1] = (__bf16)(acc[i][4 * g + 1] * osc);
+                v[2] = (__bf16)(acc[i][4 * g + 2] * osc); v[3] = (__bf16)(acc[i][4 * g + 3] * osc);
                 *reinterpret_cast<uint2*>(tile + l31 * RS + dcol * 2) = __builtin_bit_cast(uint2, v);
             }
         }
@@ -450,7 +460,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
     char* Bs = As + LA * RS;                          // phase 0: dO       phase 1: V
     float* lse2 = reinterpret_cast<float*>(Bs + LA * RS);     // phase 0 only: lse * log2(e), [LqP]
     float* dlt = lse2 + (PHASE == 0 ? LqP : 0);               // phase 0 only: delta, [LqP]
-    char* Sc = reinterpret_cast<char*>(dlt + (PHASE == 0 ? LqP : 0));   // [NW][32 rows x RS] bf16 transpose tiles
+    uint2* rkey = reinterpret_cast<uint2*>(dlt + (PHASE == 0 ? LqP : 0));      // phase 0 only: dropout row keys, [LqP]
+    char* Sc = reinterpret_cast<char*>(rkey + (PHASE == 0 ? LqP : 0));   // [NW][32 rows x RS] bf16 transpose tiles
     int* wflag = reinterpret_cast<int*>(Sc + NW * 32 * RS);
     uint8_t* kpad = reinterpret_cast<uint8_t*>(wflag + NW);
     uint8_t* modl = kpad + LkP;
@@ -460,6 +471,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
     const uint16_t* og = reinterpret_cast<const uint16_t*>(d.o) + (size_t)b * Lq * d.ldo + h * DH;
     const uint16_t* dog = reinterpret_cast<const uint16_t*>(d.d_o) + (size_t)b * Lq * d.lddo + h * DH;
     const Drop16 dp = drop16_init(d.drop_p);
+    // constant factors stay out of the per-element algebra: P~ and dP carry the keep mask only, delta is pre-divided by the
+    // dropout scale, and dK / dQ (x softmax scale x dropout scale) and dV (x dropout scale) are scaled once, when stored
+    const float inv_ds = 1.f / dp.scale, osc_dk = d.scale * dp.scale;
     const Drop dout = drop_init(d.drop_o);
 
     if constexpr (PHASE == 0) {
@@ -485,13 +499,18 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
             }
 #pragma unroll
             for (int off = 1; off < C8; off <<= 1) part += __shfl_xor(part, off);
-            if (c == 0) dlt[row] = part;
+            if (c == 0) dlt[row] = part * inv_ds;
             *reinterpret_cast<uint4*>(Bs + row * RS + c * 16) = __builtin_bit_cast(uint4, pack8(gd));
         }
         constexpr int PADC = RS / 16 - C8;
         for (int idx = t; idx < LqP * PADC; idx += NT)
             *reinterpret_cast<uint4*>(Bs + (idx / PADC) * RS + (C8 + idx % PADC) * 16) = make_uint4(0u, 0u, 0u, 0u);
-        for (int i = t; i < LqP; i += NT) lse2[i] = (i < Lq) ? d.lse[(size_t)bh_ * Lq + i] * LOG2E : 0.f;
+        for (int i = t; i < LqP; i += NT) {
+            lse2[i] = (i < Lq) ? d.lse[(size_t)bh_ * Lq + i] * LOG2E : 0.f;
+            uint32_t ka, kb;
+            dp.rowkeys((uint32_t)bh_ * (uint32_t)Lq + (uint32_t)i, ka, kb);
+            rkey[i] = make_uint2(ka, kb);
+        }
     } else {
         load_head16<DH>(As, RS, RS / 16, kg, d.ldk, Lk, LkP, t, NT);
         load_head16<DH>(Bs, RS, RS / 16, vg, d.ldv, Lk, LkP, t, NT);
@@ -513,7 +532,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
     const bool nomask = vote && !(d.flags & (MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP));
 
     const MaskCtx mk{kpad, modl, d.flags};
-    const int nqt = LqP / 32, nkt = LkP / 32, LkH = (Lk + 1) >> 1;
+    const int nqt = LqP / 32, nkt = LkP / 32;
     const uint32_t pbase = (uint32_t)bh_ * (uint32_t)Lq;
     const float c2 = d.scale * LOG2E;
     char* sct = Sc + wave * 32 * RS;
@@ -561,11 +580,11 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
             for (int s2 = 0; s2 < 2; ++s2) {
                 float pd[8], ds[8];
                 if (full) {
-                    if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
-                    else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                    if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, rkey, GRP);
+                    else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, rkey, GRP);
                 } else {
-                    if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
-                    else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                    if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, rkey, GRP);
+                    else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, rkey, GRP);
                 }
                 const bf16x8v pf = pack8(pd), sf = pack8(ds);
 #pragma unroll
@@ -575,8 +594,8 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
                 }
             }
         }
-        store_tile_T<DH, DT>(sct, RS, dKt, reinterpret_cast<uint16_t*>(d.dk) + (size_t)b * Lk * d.lddk + h * DH, d.lddk, kt * 32, Lk, lane);
-        store_tile_T<DH, DT>(sct, RS, dVt, reinterpret_cast<uint16_t*>(d.dv) + (size_t)b * Lk * d.lddv + h * DH, d.lddv, kt * 32, Lk, lane);
+        store_tile_T<DH, DT>(sct, RS, dKt, reinterpret_cast<uint16_t*>(d.dk) + (size_t)b * Lk * d.lddk + h * DH, d.lddk, kt * 32, Lk, lane, osc_dk);
+        store_tile_T<DH, DT>(sct, RS, dVt, reinterpret_cast<uint16_t*>(d.dv) + (size_t)b * Lk * d.lddv + h * DH, d.lddv, kt * 32, Lk, lane, dp.scale);
     }
 
     // ---------------- phase 1: wave owns query tile qt -> dQ             (As = K image, Bs = V image)
@@ -612,7 +631,9 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
             }
             dofr[ks] = pack8(gd);
         }
-        const float dq_ = dpart + __shfl_xor(dpart, 32);                 // delta[q]: the two half-waves hold the two halves of d
+        const float dq_ = (dpart + __shfl_xor(dpart, 32)) * inv_ds;      // delta[q] / dscale: the two half-waves hold the two halves of d
+        uint32_t ka, kb;
+        dp.rowkeys(pbase + (uint32_t)q, ka, kb);
         const float lq = (q < Lq) ? d.lse[(size_t)bh_ * Lq + q] * LOG2E : 0.f;
         f32x16 s_next, dp_next;
         auto scoresB = [&](int kt) {
@@ -631,13 +652,12 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
             if (kt + 1 < nkt) scoresB(kt + 1);
             float ds[16];
             const bool full = nomask && (kt * 32 + 32 <= Lk) && (qt * 32 + 32 <= Lq);
-            const uint32_t pair_base = (pbase + (uint32_t)q) * (uint32_t)LkH;
             if (full) {
-                if (dp.on) bwdB_tile<true, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
-                else bwdB_tile<true, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
+                if (dp.on) bwdB_tile<true, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, ka, kb);
+                else bwdB_tile<true, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, ka, kb);
             } else {
-                if (dp.on) bwdB_tile<false, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
-                else bwdB_tile<false, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
+                if (dp.on) bwdB_tile<false, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, ka, kb);
+                else bwdB_tile<false, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, ka, kb);
             }
             const bf16x8v sf[2] = {pack8(ds), pack8(ds + 8)};
 #pragma unroll
@@ -646,7 +666,7 @@ __global__ __launch_bounds__(NW * 64) void attn_bwd_bf16_kernel(const mmfm_attn_
                 for (int s2 = 0; s2 < 2; ++s2)
                     dQt[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(As, RS, kt * 32 + 16 * s2, i * 32, lane), sf[s2], dQt[i], 0, 0, 0);
         }
-        store_tile_T<DH, DT>(sct, RS, dQt, reinterpret_cast<uint16_t*>(d.dq) + (size_t)b * Lq * d.lddq + h * DH, d.lddq, qt * 32, Lq, lane);
+        store_tile_T<DH, DT>(sct, RS, dQt, reinterpret_cast<uint16_t*>(d.dq) + (size_t)b * Lq * d.lddq + h * DH, d.lddq, qt * 32, Lq, lane, osc_dk);
     }
 }
 
@@ -684,7 +704,8 @@ __global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_
     char* Bs = As + LqP * RS;                         // dO image (output dropout applied)
     float* lse2 = reinterpret_cast<float*>(Bs + LqP * RS);
     float* dlt = lse2 + LqP;
-    char* stg = reinterpret_cast<char*>(dlt + LqP);   // [2][CW][32 keys x TS] dS^T tiles; first the K image (prologue only)
+    uint2* rkey = reinterpret_cast<uint2*>(dlt + LqP);        // dropout row keys per query
+    char* stg = reinterpret_cast<char*>(rkey + LqP);  // [2][CW][32 keys x TS] dS^T tiles; first the K image (prologue only)
     char* sc7 = stg + 2 * CW * TILE;                  // [32 x RS] dQ transpose tile of wave 7
     int* wflag = reinterpret_cast<int*>(sc7 + 32 * RS);
     uint8_t* kpad = reinterpret_cast<uint8_t*>(wflag + NW);
@@ -695,6 +716,9 @@ __global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_
     const uint16_t* og = reinterpret_cast<const uint16_t*>(d.o) + (size_t)b * Lq * d.ldo + h * DH;
     const uint16_t* dog = reinterpret_cast<const uint16_t*>(d.d_o) + (size_t)b * Lq * d.lddo + h * DH;
     const Drop16 dp = drop16_init(d.drop_p);
+    // constant factors stay out of the per-element algebra: P~ and dP carry the keep mask only, delta is pre-divided by the
+    // dropout scale, and dK / dQ (x softmax scale x dropout scale) and dV (x dropout scale) are scaled once, when stored
+    const float inv_ds = 1.f / dp.scale, osc_dk = d.scale * dp.scale;
     const Drop dout = drop_init(d.drop_o);
 
     load_head16<DH>(As, RS, RS / 16, qg, d.ldq, Lq, LqP, t, NT);
@@ -719,13 +743,18 @@ __global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_
         }
 #pragma unroll
         for (int off = 1; off < C8; off <<= 1) part += __shfl_xor(part, off);
-        if (c == 0) dlt[row] = part;
+        if (c == 0) dlt[row] = part * inv_ds;
         *reinterpret_cast<uint4*>(Bs + row * RS + c * 16) = __builtin_bit_cast(uint4, pack8(gd));
     }
     constexpr int PADC = RS / 16 - C8;
     for (int idx = t; idx < LqP * PADC; idx += NT)
         *reinterpret_cast<uint4*>(Bs + (idx / PADC) * RS + (C8 + idx % PADC) * 16) = make_uint4(0u, 0u, 0u, 0u);
-    for (int i = t; i < LqP; i += NT) lse2[i] = (i < Lq) ? d.lse[(size_t)bh_ * Lq + i] * LOG2E : 0.f;
+    for (int i = t; i < LqP; i += NT) {
+        lse2[i] = (i < Lq) ? d.lse[(size_t)bh_ * Lq + i] * LOG2E : 0.f;
+        uint32_t ka, kb;
+        dp.rowkeys((uint32_t)bh_ * (uint32_t)Lq + (uint32_t)i, ka, kb);
+        rkey[i] = make_uint2(ka, kb);
+    }
     int allk = 1;
     for (int i = t; i < LkP; i += NT) {
         const uint8_t v = (i < Lk && d.keypad) ? d.keypad[(size_t)b * Lk + i] : 0;
@@ -743,8 +772,7 @@ __global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_
     const bool nomask = vote && !(d.flags & (MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP));
 
     const MaskCtx mk{kpad, modl, d.flags};
-    const int nqt = LqP / 32, nkt = LkP / 32, LkH = (Lk + 1) >> 1;        // nkt <= CW (launcher)
-    const uint32_t pbase = (uint32_t)bh_ * (uint32_t)Lq;
+    const int nqt = LqP / 32, nkt = LkP / 32;        // nkt <= CW (launcher)
     const float c2 = d.scale * LOG2E;
 
     if (wave < CW) {
@@ -798,11 +826,11 @@ __global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_
                     if (2 * s2 >= GRP) continue;
                     float pd[8], ds[8];
                     if (full) {
-                        if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
-                        else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                        if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, rkey, GRP);
+                        else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, rkey, GRP);
                     } else {
-                        if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
-                        else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                        if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, rkey, GRP);
+                        else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2, dlt, qt, key, kh, Lq, Lk, mk, dp, rkey, GRP);
                     }
                     const bf16x8v pf = pack8(pd), sf = pack8(ds);
                     // dS^T[key = lane][q]: elements 0..3 are queries 16*s2 + 4*kh + 0..3, elements 4..7 the same + 8
@@ -821,9 +849,9 @@ __global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_
         // Q / dO images are dead (every compute wave passed the last barrier): rows [32w, 32w+32) carry this wave's stores
         if (active) {
             store_tile_T<DH, DT>(As + 32 * wave * RS, RS, dKt, reinterpret_cast<uint16_t*>(d.dk) + (size_t)b * Lk * d.lddk + h * DH, d.lddk,
-                                 kt * 32, Lk, lane);
+                                 kt * 32, Lk, lane, osc_dk);
             store_tile_T<DH, DT>(Bs + 32 * wave * RS, RS, dVt, reinterpret_cast<uint16_t*>(d.dv) + (size_t)b * Lk * d.lddv + h * DH, d.lddv,
-                                 kt * 32, Lk, lane);
+                                 kt * 32, Lk, lane, dp.scale);
         }
     } else {
         // ---------------- wave 7: K^T operands of every key tile, hardware-transposed out of the K image and kept for the
@@ -856,14 +884,14 @@ __global__ __launch_bounds__(BW1_NW * 64, DH <= 32 ? 4 : 2) void attn_bwd1_bf16_
                     }
                 }
             }
-            store_tile_T<DH, DT>(sc7, RS, dQt, dqg, d.lddq, qt * 32, Lq, lane);
+            store_tile_T<DH, DT>(sc7, RS, dQt, dqg, d.lddq, qt * 32, Lq, lane, osc_dk);
         }
     }
 }
 
 size_t bwd1_lds(int Lq, int Lk, int dh) {
     const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31, RS = dh * 2 + 16;
-    return (size_t)2 * LqP * RS + (size_t)2 * LqP * 4 + (size_t)2 * BW1_CW * BW1_TILE + (size_t)32 * RS + BW1_NW * 4 + LkP + std::max(Lq, Lk) + 64;
+    return (size_t)2 * LqP * RS + (size_t)4 * LqP * 4 + (size_t)2 * BW1_CW * BW1_TILE + (size_t)32 * RS + BW1_NW * 4 + LkP + std::max(Lq, Lk) + 64;
 }
 // shapes the single-pass backward takes: one key tile per compute wave, the K image fits the staging area, the dK/dV
 // store tiles fit the Q/dO images
@@ -922,12 +950,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_tiled_kernel(const mmfm_
     const Drop16 dp = drop16_init(d.drop_p);
     const Drop dout = drop_init(d.drop_o);
     float* sc = Sc + wave * 32 * SLD;
-    const int nqt = (Lq + 31) / 32, LkH = (Lk + 1) >> 1;
+    const int nqt = (Lq + 31) / 32;
     const float c2 = d.scale * LOG2E;
     const int qt = blockIdx.y * NW + wave;
     const bool active = qt < nqt;                      // inactive waves still take part in the chunk barriers
     const int q0 = qt * 32, q = q0 + l31;
-    const uint32_t pair_base = ((uint32_t)bh_ * (uint32_t)Lq + (uint32_t)q) * (uint32_t)LkH;
+    uint32_t ka, kb;                                       // dropout row keys of this lane's query
+    dp.rowkeys((uint32_t)bh_ * (uint32_t)Lq + (uint32_t)q, ka, kb);
     bf16x8v qf[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -964,11 +993,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_tiled_kernel(const mmfm_
             bool live;
             const int nk = min(32, Lk - kt * 32), G = (nk + 7) >> 3;
             if (nomask && (nk & 7) == 0)
-                live = dp.on ? fwd_tile<true, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G)
-                             : fwd_tile<true, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G);
+                live = dp.on ? fwd_tile<true, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, ka, kb, G)
+                             : fwd_tile<true, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, ka, kb, G);
             else
-                live = dp.on ? fwd_tile<false, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G)
-                             : fwd_tile<false, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, pair_base, G);
+                live = dp.on ? fwd_tile<false, true>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, ka, kb, G)
+                             : fwd_tile<false, false>(st, c2, m_run, l_run, alpha, pd, q, Lq, Lk, kt, kh, mk, dp, ka, kb, G);
             if (!live) return;
             const bf16x8v pf0 = pack8(pd), pf1 = pack8(pd + 8);
             const bool rescale = !__all(alpha == 1.f);
@@ -996,7 +1025,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_bf16_tiled_kernel(const mmfm_
     }
     if (!active) return;                               // no barrier below
     const float l_tot = l_run + __shfl_xor(l_run, 32);
-    const float inv = 1.f / l_tot;
+    const float inv = dp.scale / l_tot;
     if (kh == 0 && q < Lq) d.lse[(size_t)bh_ * Lq + q] = m_run * LN2 + __logf(l_tot);
     wave_lds_fence();
 #pragma unroll
@@ -1034,7 +1063,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
     char* Bs = As + TCH16 * RS;                       // phase 0: dO chunk    phase 1: V chunk
     float* lse2 = reinterpret_cast<float*>(Bs + TCH16 * RS);   // phase 0: lse * log2(e) of the chunk  [TCH16]
     float* dlt = lse2 + TCH16;                                 // phase 0: delta of the chunk          [TCH16]
-    char* Sc = reinterpret_cast<char*>(dlt + TCH16);           // [NW][32 rows x RS] output transpose tiles
+    uint2* rkey = reinterpret_cast<uint2*>(dlt + TCH16);       // phase 0: dropout row keys of the chunk     [TCH16]
+    char* Sc = reinterpret_cast<char*>(rkey + TCH16);          // [NW][32 rows x RS] output transpose tiles
     int* wflag = reinterpret_cast<int*>(Sc + NW * 32 * RS);
     uint8_t* kpad = reinterpret_cast<uint8_t*>(wflag + NW);
     uint8_t* modl = kpad + LkP;
@@ -1044,6 +1074,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
     const uint16_t* og = reinterpret_cast<const uint16_t*>(d.o) + (size_t)b * Lq * d.ldo + h * DH;
     const uint16_t* dog = reinterpret_cast<const uint16_t*>(d.d_o) + (size_t)b * Lq * d.lddo + h * DH;
     const Drop16 dp = drop16_init(d.drop_p);
+    // constant factors stay out of the per-element algebra: P~ and dP carry the keep mask only, delta is pre-divided by the
+    // dropout scale, and dK / dQ (x softmax scale x dropout scale) and dV (x dropout scale) are scaled once, when stored
+    const float inv_ds = 1.f / dp.scale, osc_dk = d.scale * dp.scale;
     const Drop dout = drop_init(d.drop_o);
 
     int allk = 1;
@@ -1063,7 +1096,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
     const bool nomask = vote && !(d.flags & (MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP));
 
     const MaskCtx mk{kpad, modl, d.flags};
-    const int LkH = (Lk + 1) >> 1;
     const uint32_t pbase = (uint32_t)bh_ * (uint32_t)Lq;
     const float c2 = d.scale * LOG2E;
     char* sct = Sc + wave * 32 * RS;
@@ -1112,17 +1144,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
                 }
 #pragma unroll
                 for (int off = 1; off < C8; off <<= 1) part += __shfl_xor(part, off);
-                if (c == 0) dlt[row] = part;
+                if (c == 0) dlt[row] = part * inv_ds;
                 *reinterpret_cast<uint4*>(Bs + row * RS + c * 16) = __builtin_bit_cast(uint4, pack8(gd));
             }
             constexpr int PADC = RS / 16 - C8;
             for (int idx = t; idx < rows * PADC; idx += NT)
                 *reinterpret_cast<uint4*>(Bs + (idx / PADC) * RS + (C8 + idx % PADC) * 16) = make_uint4(0u, 0u, 0u, 0u);
-            for (int i = t; i < rows; i += NT) lse2[i] = (c0 + i < Lq) ? d.lse[(size_t)bh_ * Lq + c0 + i] * LOG2E : 0.f;
+            for (int i = t; i < rows; i += NT) {
+                lse2[i] = (c0 + i < Lq) ? d.lse[(size_t)bh_ * Lq + c0 + i] * LOG2E : 0.f;
+                uint32_t ka, kb;
+                dp.rowkeys((uint32_t)bh_ * (uint32_t)Lq + (uint32_t)(c0 + i), ka, kb);
+                rkey[i] = make_uint2(ka, kb);
+            }
             __syncthreads();
             if (!active) continue;
             const float* lse2g = lse2 - c0;            // indexed by the GLOBAL query
             const float* dltg = dlt - c0;
+            const uint2* rkeyg = rkey - c0;
             for (int ql = 0; ql < rows / 32; ++ql) {
                 const int qt = c0 / 32 + ql;
                 f32x16 s, dpv;
@@ -1141,11 +1179,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
                     if (2 * s2 >= GRP) continue;
                     float pd[8], ds[8];
                     if (full) {
-                        if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
-                        else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                        if (dp.on) bwdA_half<true, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, rkeyg, GRP);
+                        else bwdA_half<true, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, rkeyg, GRP);
                     } else {
-                        if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
-                        else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, pbase, LkH, GRP);
+                        if (dp.on) bwdA_half<false, true>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, rkeyg, GRP);
+                        else bwdA_half<false, false>(s, dpv, s2, pd, ds, c2, d.scale, lse2g, dltg, qt, key, kh, Lq, Lk, mk, dp, rkeyg, GRP);
                     }
                     const bf16x8v pf = pack8(pd), sf = pack8(ds);
 #pragma unroll
@@ -1157,8 +1195,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
             }
         }
         if (!active) return;
-        store_tile_T<DH, DT>(sct, RS, dKt, reinterpret_cast<uint16_t*>(d.dk) + (size_t)b * Lk * d.lddk + h * DH, d.lddk, kt * 32, Lk, lane);
-        store_tile_T<DH, DT>(sct, RS, dVt, reinterpret_cast<uint16_t*>(d.dv) + (size_t)b * Lk * d.lddv + h * DH, d.lddv, kt * 32, Lk, lane);
+        store_tile_T<DH, DT>(sct, RS, dKt, reinterpret_cast<uint16_t*>(d.dk) + (size_t)b * Lk * d.lddk + h * DH, d.lddk, kt * 32, Lk, lane, osc_dk);
+        store_tile_T<DH, DT>(sct, RS, dVt, reinterpret_cast<uint16_t*>(d.dv) + (size_t)b * Lk * d.lddv + h * DH, d.lddv, kt * 32, Lk, lane, dp.scale);
     } else {
         const int qt = blockIdx.y * NW + wave;
         const bool active = qt < LqP / 32;
@@ -1192,9 +1230,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
             }
             dofr[ks] = pack8(gd);
         }
-        const float dq_ = dpart + __shfl_xor(dpart, 32);
+        const float dq_ = (dpart + __shfl_xor(dpart, 32)) * inv_ds;
+        uint32_t ka, kb;
+        dp.rowkeys(pbase + (uint32_t)q, ka, kb);
         const float lq = (active && q < Lq) ? d.lse[(size_t)bh_ * Lq + q] * LOG2E : 0.f;
-        const uint32_t pair_base = (pbase + (uint32_t)q) * (uint32_t)LkH;
         for (int c0 = 0; c0 < LkP; c0 += TCH16) {
             const int rows = min(TCH16, LkP - c0);
             __syncthreads();
@@ -1216,11 +1255,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
                 float ds[16];
                 const bool full = nomask && (kt * 32 + 32 <= Lk) && (qt * 32 + 32 <= Lq);
                 if (full) {
-                    if (dp.on) bwdB_tile<true, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
-                    else bwdB_tile<true, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
+                    if (dp.on) bwdB_tile<true, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, ka, kb);
+                    else bwdB_tile<true, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, ka, kb);
                 } else {
-                    if (dp.on) bwdB_tile<false, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
-                    else bwdB_tile<false, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, pair_base);
+                    if (dp.on) bwdB_tile<false, true>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, ka, kb);
+                    else bwdB_tile<false, false>(s, dpv, ds, c2, d.scale, lq, dq_, q, kt, kh, Lq, Lk, mk, dp, ka, kb);
                 }
                 const bf16x8v sf[2] = {pack8(ds), pack8(ds + 8)};
 #pragma unroll
@@ -1231,7 +1270,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_tiled_kernel(const mmfm_
             }
         }
         if (!active) return;
-        store_tile_T<DH, DT>(sct, RS, dQt, reinterpret_cast<uint16_t*>(d.dq) + (size_t)b * Lq * d.lddq + h * DH, d.lddq, qt * 32, Lq, lane);
+        store_tile_T<DH, DT>(sct, RS, dQt, reinterpret_cast<uint16_t*>(d.dq) + (size_t)b * Lq * d.lddq + h * DH, d.lddq, qt * 32, Lq, lane, osc_dk);
     }
 }
 
@@ -1241,7 +1280,7 @@ size_t fwd_tiled16_lds(int Lq, int Lk, int dh) {
 }
 size_t bwd_tiled16_lds(int Lq, int Lk, int dh) {
     const int LkP = (Lk + 31) & ~31, RS = dh * 2 + 16;
-    return (size_t)2 * TCH16 * RS + (size_t)2 * TCH16 * 4 + (size_t)4 * 32 * RS + 16 + LkP + std::max(Lq, Lk) + 64;
+    return (size_t)2 * TCH16 * RS + (size_t)4 * TCH16 * 4 + (size_t)4 * 32 * RS + 16 + LkP + std::max(Lq, Lk) + 64;
 }
 
 // waves per workgroup (MMFM_ATTN_FWD_WAVES / MMFM_ATTN_BWD_WAVES = 4 or 8).  Smaller workgroups let more of them
@@ -1261,7 +1300,7 @@ size_t fwd_lds(int Lq, int Lk, int dh, int nw) {
 size_t bwd_lds(int Lq, int Lk, int dh, int nw, int phase) {
     const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31, RS = dh * 2 + 16;
     const size_t images = (size_t)2 * (phase == 0 ? LqP : LkP) * RS;
-    return images + (phase == 0 ? (size_t)2 * LqP * 4 : 0) + (size_t)nw * 32 * RS + LkP + std::max(Lq, Lk) + 64;
+    return images + (phase == 0 ? (size_t)4 * LqP * 4 : 0) + (size_t)nw * 32 * RS + LkP + std::max(Lq, Lk) + 64;
 }
 
 // the attribute belongs to the (device, kernel) pair: a process that drives several GPUs must opt in on each
