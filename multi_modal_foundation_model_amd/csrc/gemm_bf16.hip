@@ -168,7 +168,9 @@ __device__ __forceinline__ void stg8(uint16_t* p, uint4 v, bool a16, bool hi, bo
     if (hi) *reinterpret_cast<uint2*>(p + 4) = make_uint2(v.z, v.w);
 }
 
-template <typename TO>
+// EPI_LOADS = false: the instantiation of the persistent bf16-output kernel, launched only without a saved pre-activation /
+// residual operand (their registers would sit on top of the next tile's prefetched slice)
+template <typename TO, bool EPI_LOADS = true>
 __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&acc)[2][2], char* smem, int m0, int n0, int z, int vec_epi,
                                               int t, int wm, int wn, int kh, int l31) {
     // ---- epilogue.  Fast path (row-aligned shapes): the fp32 tile is staged through LDS half a tile at a time
@@ -200,7 +202,7 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
             // latency runs under the two barriers and the LDS round trip instead of in front of every chunk (one 16-B load,
             // use, next load ... was 4 exposed round trips per half: dg GEMM 193 us, down-projection 145 us at B = 1024)
             uint4 gu[4], gr[4];
-            if (bf_path) {
+            if (EPI_LOADS && bf_path) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int m = m0 + half * 64 + ((t + 256 * c) >> 4);
@@ -251,7 +253,7 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = softsign_f(v[e]) * d.act_scale;
                 }
-                if (d.gradmul_pre) {
+                if (EPI_LOADS && d.gradmul_pre) {
                     float u[8];
                     unpack8(gu[c], u);
                     if (d.act == 3) mul_gelu_grad_n<8>(v, u);
@@ -265,7 +267,7 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
 #pragma unroll
                     for (int e = 0; e < 8; e += 2) dr.apply2(v[e], v[e + 1], base + e);      // n and N are even here, so base is
                 }
-                if (d.residual) {
+                if (EPI_LOADS && d.residual) {
                     float u[8];
                     unpack8(gr[c], u);
 #pragma unroll
@@ -408,7 +410,7 @@ __global__ __launch_bounds__(NTHREADS, BK == 64 ? 3 : 2) void gemm_bf16_kernel(c
                 d.colsum[(d.splits > 1 ? (size_t)z * d.slab_stride : 0) + m0 + t] = sum;
             }
         }
-        epilogue_tile<TO>(d, acc, smem, m0, n0, z, vec_epi, t, wm, wn, kh, l31);
+        epilogue_tile<TO, !(PERSIST && sizeof(TO) == 2)>(d, acc, smem, m0, n0, z, vec_epi, t, wm, wn, kh, l31);
         if (!more) break;
         w = wn_; m0 = m0n; n0 = n0n; z = zn; kbeg = kbegn; kend = kendn;
     }
@@ -437,7 +439,6 @@ int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     const int total_items = tiles * d.splits;
     static const int wg_per_cu = [] { const char* e = getenv("MMFM_GEMM_WG_PER_CU"); const int v = e ? atoi(e) : 3; return v > 0 ? v : 3; }();
     const bool f32out = d.c_f32 || d.splits > 1;
-    dim3 grid(f32out ? std::min(total_items, 256 * wg_per_cu) : total_items), block(NTHREADS);   // persistent: 3 resident workgroups per CU
     // vector epilogue needs 16-B aligned 8-column chunks of every tensor it touches
     auto al16 = [](const void* p) { return p == nullptr || (uintptr_t)p % 16 == 0; };
     const int vec8 = (d.N % 8 == 0) && (d.ldc % 8 == 0) && al16(d.C) && al16(d.pre_out) && al16(d.gradmul_pre) && al16(d.bias) &&
@@ -452,10 +453,18 @@ int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     // pre-activation LOADED non-temporally
     static const int nt_env = [] { const char* e = getenv("MMFM_GEMM_NT"); return e ? atoi(e) : 3; }();
     const int vecf = vec | ((nt_env & 1) ? 4096 : 0) | ((nt_env & 2) ? 8192 : 0) | ((nt_env & 4) ? 16384 : 0) | ((nt_env & 8) ? 32768 : 0);
+    // bf16-output launches without epilogue operands and with a short reduction are persistent too (the next tile's first
+    // K-slice is in flight during the epilogue): qkv x.W^T 160 -> 151 us, its dX 139 -> 131 us in the B = 1024 step; with
+    // K >= 1336 (token embedding) the prefetch registers spill and it measured 30 % SLOWER, hence the K bound.
+    // MMFM_GEMM_PERSIST_BF16 = 0 turns it off.
+    static const int persist_bf16 = [] { const char* e = getenv("MMFM_GEMM_PERSIST_BF16"); return e ? atoi(e) : 1; }();
+    const bool pb = !f32out && persist_bf16 && !d.gradmul_pre && !d.residual && !d.pre_out && (vec & 1) && d.K <= 768;
+    dim3 grid((f32out || pb) ? std::min(total_items, 256 * wg_per_cu) : total_items), block(NTHREADS);   // persistent: 3 resident workgroups per CU
     // occupancy probe: unused dynamic LDS bytes per workgroup (60000 -> one workgroup per CU less, 100000 -> one per CU)
     static const int pad_lds = [] { const char* e = getenv("MMFM_GEMM_PAD_LDS"); return e ? atoi(e) : 0; }();
 #define LAUNCH2(ARC, BRC, BKV)                                                                                    \
     if (f32out) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, float, BKV>), grid, block, pad_lds, st, d, aA, aB, vecf, total_items);  \
+    else if (pb) hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t, BKV, true>), grid, block, pad_lds, st, d, aA, aB, vecf, total_items); \
     else hipLaunchKernelGGL((gemm_bf16_kernel<ARC, BRC, uint16_t, BKV>), grid, block, pad_lds, st, d, aA, aB, vecf, total_items);
 #define LAUNCH(ARC, BRC) if (BKsel == 128) { LAUNCH2(ARC, BRC, 128) } else { LAUNCH2(ARC, BRC, 64) }
     if (d.a_kcontig && d.b_kcontig) { LAUNCH(false, false) }

@@ -622,7 +622,8 @@ extern "C" int mmfm_mlp_fwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     const mmfm_mlp_desc d = *dp;
     if (int rc = check(d, false)) return rc;
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
-    static const int v1 = [] { const char* e = getenv("MMFM_MLP_V1"); return e ? atoi(e) : 0; }();
+    // measured in the B = 1024 step (p = 0.4): wave-pair forward 257 us, one-wave forward 300 us -> pairs by default
+    static const int v1 = [] { const char* e = getenv("MMFM_MLP_FWD_V1"); return e ? atoi(e) : 0; }();
     if (!v1) hipLaunchKernelGGL(mlp_fwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), 0, (hipStream_t)stream, d);
     else hipLaunchKernelGGL(mlp_fwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), 0, (hipStream_t)stream, d);
     MMFM_LAUNCH_CHECK("mmfm_mlp_fwd");
@@ -633,7 +634,8 @@ extern "C" int mmfm_mlp_bwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     const mmfm_mlp_desc d = *dp;
     if (int rc = check(d, true)) return rc;
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
-    static const int v1 = [] { const char* e = getenv("MMFM_MLP_V1"); return e ? atoi(e) : 0; }();
+    // ... and the backward the other way round: one wave per tile 478 us, wave pairs 539 us -> one-wave by default
+    static const int v1 = [] { const char* e = getenv("MMFM_MLP_BWD_V1"); return e ? atoi(e) : 1; }();
     if (!v1) hipLaunchKernelGGL(mlp_bwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), 0, (hipStream_t)stream, d);
     else hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), 0, (hipStream_t)stream, d);
     MMFM_LAUNCH_CHECK("mmfm_mlp_bwd");
