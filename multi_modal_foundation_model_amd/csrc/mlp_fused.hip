@@ -27,8 +27,8 @@ __device__ unsigned long long mmfm_probe_acc[16];
 #define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_a[i] += n_ - st_t; st_t = n_; } while (0)
 #define STAMP_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&mmfm_probe_acc[i_], st_a[i_]); } while (0)
 extern "C" int mmfm_probe_read(unsigned long long* host8, int reset) {
-    hipMemcpyFromSymbol(host8, HIP_SYMBOL(mmfm_probe_acc), 64);
-    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(mmfm_probe_acc), z, 128); }
+    (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(mmfm_probe_acc), 64);
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mmfm_probe_acc), z, 128); }
     return 0;
 }
 #else
@@ -163,6 +163,10 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
     STAMP_FLUSH;
 }
 
+// MMFM_PROBE (diagnostic builds only, scripts/probe/build_probe.sh): bit 0 drops the g / du stores of the loop, bit 1 the GELU algebra
+#ifndef MMFM_PROBE
+#define MMFM_PROBE 0
+#endif
 __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
     __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + 3 * NW * STG_BYTES + 512 * 4];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
@@ -192,6 +196,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
     const uint32_t lddyb = d.lddy * 2, lddxb = d.lddx * 2;
     RING_DECL(NT);
     RING_START(smem, my_passes * 48, src);
+    STAMP_DECL;
     for (int pi = 0; pi < my_passes; ++pi) {
         const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
         const uint32_t row = wrow0 + m;
@@ -211,31 +216,40 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
         f32x16 DH[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) DH[i] = zero16();
+        STAMP(0);
         for (int ti = 0; ti < 16; ++ti) {
             const int tt = (ti + rot) & 15;
             const char* slot;
             RING_STEP(src, slot);
+            STAMP(1);
             f32x16 U = mma16(slot, x, zero16(), m, h);
             add_vec(U, lb_up, tt, h);
+            STAMP(2);
             RING_STEP(src, slot);
+            STAMP(1);
             f32x16 DG = mma16(slot, t1, zero16(), m, h);
+            STAMP(2);
             f32x16 Gt;
-            gelu_fwd_bwd16(U, Gt, DG);
+            if (MMFM_PROBE & 2) Gt = U; else gelu_fwd_bwd16(U, Gt, DG);
             opnd d0, d1;
             acc_to_opnd(DG, d0, d1);
+            STAMP(3);
             RING_SYNC_WRITE(src);
+            STAMP(1);
             stage_tile(stg_g, ti & 1, m, h, Gt);
             stage_tile(stg_du, ti & 1, m, h, DG);
-            if (ti & 1) {                                     // uniform: the pair (tt-1, tt) is complete -> whole 128-B lines
+            if ((ti & 1) && !(MMFM_PROBE & 1)) {              // uniform: the pair (tt-1, tt) is complete -> whole 128-B lines
                 flush_lines<true>(stg_g, G, wrow0, 1024u, 64u * (tt - 1), lane);
                 flush_lines<true>(stg_du, DU, wrow0, 1024u, 64u * (tt - 1), lane);
             }
+            STAMP(4);
             RING_FETCH(src, slot);
 #pragma unroll
             for (int t2 = 0; t2 < 8; ++t2) {
                 DH[t2] = mfma(wfragB(slot, t2, 0, m, h), d0, DH[t2]);
                 DH[t2] = mfma(wfragB(slot, t2, 1, m, h), d1, DH[t2]);
             }
+            STAMP(5);
         }
         // LayerNorm backward on the row: dx = dy + rstd * (dh - mean(dh) - x_hat * mean(dh * x_hat))
         float s1 = 0.f, s2 = 0.f;
@@ -275,7 +289,9 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
             stage_tile(stg, 1, m, h, o[1]);
             flush_lines<false>(stg, DX, wrow0, lddxb, 128u * tp, lane);
         }
+        STAMP(6);
     }
+    STAMP_FLUSH;
 }
 
 // ------------------------------------------------------------------------------------------------ wave-pair versions

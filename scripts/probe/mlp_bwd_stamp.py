@@ -1,0 +1,37 @@
+"""Phase breakdown of mlp_bwd (one-wave kernel) from the stamped diagnostic library (scripts/probe/build_stamp.sh)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["MMFM_LIB"] = os.path.join(ROOT, "multi_modal_foundation_model_amd", "libmmfm_stamp.so")
+os.environ["MMFM_MLP_BWD_V1"] = "1"
+sys.path.insert(0, ROOT)
+import torch
+from multi_modal_foundation_model_amd import ops, _lib as L
+R = 204800
+BF = torch.bfloat16
+def rnd(*s, sc=1.0): return torch.randn(*s, device="cuda") * sc
+def prep(W, g=None, b=None, bias=None):
+    N, K = W.shape
+    e = dict(W=W, gamma=g, beta=b, bias=bias, Wp=torch.empty(N, K, device="cuda", dtype=BF), WpT=torch.empty(K, N, device="cuda", dtype=BF), bp=torch.empty(N, device="cuda"))
+    tb, n, tiles = ops.prep_table([e], "cuda"); ops.prep_weights(tb, n, tiles); return e
+g, bt = 1 + 0.1 * rnd(256), 0.1 * rnd(256)
+xhat, rstd = rnd(R, 256).to(BF), torch.rand(R, device="cuda") + 0.5
+up, dn = prep(rnd(512, 256, sc=1 / 16), g, bt, 0.1 * rnd(512)), prep(rnd(256, 512, sc=1 / 22), None, None, 0.1 * rnd(256))
+dy = rnd(R, 256).to(BF)
+t1, gg, du, dx = (torch.empty(R, n, device="cuda", dtype=BF) for n in (256, 512, 512, 256))
+lib = L.lib()
+lib.mmfm_probe_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
+buf = (C.c_ulonglong * 8)()
+names = ["pass prologue (x_hat, dy rows, dropout, t1 out)", "ring steps: wait + barrier + LDS write (+ fetch)", "up / dg MFMAs", "GELU algebra + cvt",
+         "stage g, du + line stores", "dh MFMAs (+ fetch issue)", "pass epilogue (LN backward, dx out)", "-"]
+for p in (0.0, 0.4):
+    st = torch.zeros(2, dtype=torch.int32, device="cuda"); ops.rng_seed(st, 1)
+    d = ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], drop=ops.dropout(st, 3, p) if p else None, xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpT"],
+                     t1=t1, g=gg, du=du, dx=dx)
+    ops.mlp_bwd(d); torch.cuda.synchronize(); lib.mmfm_probe_read(buf, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); ops.mlp_bwd(d); e1.record(); torch.cuda.synchronize()
+    lib.mmfm_probe_read(buf, 1)
+    tot = sum(buf[i] for i in range(8))
+    print(f"mlp_bwd p={p}: {e0.elapsed_time(e1)*1e3:.1f} us; wave-0 cycles per workgroup (256 WGs), total {tot/256:.0f}")
+    for i, n in enumerate(names[:7]):
+        print(f"   {n:52s} {buf[i]/256:10.0f}  ({100*buf[i]/tot:4.1f} %)")
