@@ -615,3 +615,29 @@ def test_attention_bf16_dropout_consistency(ops, L, dh):
     ops.attn_bwd(desc)
     dv = dqkv[:, 2 * H:].float().view(B, L, heads, dh)[..., 0]
     close(dv.sum(1), o.float().view(B, L, heads, dh)[..., 0].sum(1), rtol=2e-2, atol=0.5, msg="bf16 fwd/bwd dropout mask agree")
+
+
+@pytest.mark.parametrize("M,N,K,kc", [(204800 + 37, 768, 256, 1), (204800 + 37, 256, 768, 0), (204800, 512, 256, 1)])
+def test_gemm_bf16_full_size_many_tiles_per_workgroup(ops, M, N, K, kc):
+    """BASELINE configs[1] row count (B = 1024 x 200 tokens): 4,800-9,600 output tiles, so the persistent bf16-output kernel walks
+    several tiles per workgroup with the next tile's first K-slice prefetched during the epilogue.  Sampled rows against torch fp64,
+    and the first rows bit for bit against a launch small enough to be one tile per workgroup."""
+    x, b = bf(rnd(M, K, seed=1)), rnd(N, seed=3)
+    w = bf(rnd(N, K, seed=2, scale=K ** -0.5)) if kc else bf(rnd(K, N, seed=2, scale=K ** -0.5))
+    y = torch.full((M + 2, N), 9.0, device="cuda", dtype=torch.bfloat16)
+    g = torch.Generator().manual_seed(0)
+    idx = torch.cat([torch.arange(0, 300), torch.randint(0, M, (2048,), generator=g), torch.arange(M - 300, M)]).unique().cuda()
+    if kc:
+        ops.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b)
+        ref = x[idx].double() @ w.double().T + b.double()
+    else:
+        ops.gemm(x, w, y, M, N, K, lda=K, ldb=N, ldc=N, b_kcontig=0)
+        ref = x[idx].double() @ w.double()
+    close_bf16(y[idx], ref, f"bf16 full-size {M}x{N}x{K}")
+    assert torch.all(y[M:] == 9.0)
+    ys = torch.empty(1024, N, device="cuda", dtype=torch.bfloat16)
+    if kc:
+        ops.gemm(x[:1024], w, ys, 1024, N, K, lda=K, ldb=K, ldc=N, bias=b)
+    else:
+        ops.gemm(x[:1024], w, ys, 1024, N, K, lda=K, ldb=N, ldc=N, b_kcontig=0)
+    assert torch.equal(ys, y[:1024])

@@ -203,3 +203,75 @@ def test_ln_linear_grad_matches_autograd(ops):
     ops.ln_linear_grad(Gdb, W.detach().float().contiguous(), g.detach().float().contiguous(), bt.detach().float().contiguous(), N, K, dW, db, dg, dbt,
                        ws, accumulate_ln=True)                                      # same workspace: the tickets re-armed themselves
     torch.testing.assert_close(dg.double(), 2 * g.grad, rtol=1e-4, atol=4e-4)
+
+
+# ------------------------------------------------------------------------------------ BASELINE configs[1] row count
+# R = 1024 x 200 (+ a ragged tail): every workgroup walks several 128-row passes (the weight ring runs across pass boundaries,
+# chunk rotation, tail masking), which the small cases above never reach.  Checked on a sample of rows against torch fp64 and,
+# row-local ops being position independent, bit for bit against a small launch over the first rows.
+R_FULL = 1024 * 200 + 37
+
+
+def sample_rows(R, n=1536, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.cat([torch.arange(0, 200), torch.randint(0, R, (n,), generator=g), torch.arange(R - 300, R)]).unique()
+    return idx.cuda()
+
+
+def test_full_size_rowgemm_variants(ops):
+    R = R_FULL
+    idx = sample_rows(R)
+    x = (rnd(R, 256, seed=1) * 2 + rnd(R, 1, seed=5)).to(BF)
+    res = rnd(R, 256, seed=4).to(BF)
+    # out_proj-type: plain product + bias + residual
+    W, b = rnd(256, 256, seed=2, scale=1 / 16).to(BF), rnd(256, seed=3)
+    y = torch.full((R + 3, 256), 7.0, device="cuda", dtype=BF)
+    ops.rowgemm(x, W, y, R, 256, 256, bias=b, residual=res, ldr=256)
+    check(y[idx], x[idx].double() @ W.double().T + b.double() + res[idx].double(), 4e-3, "full-size rowgemm")
+    assert torch.all(y[R:] == 7.0)
+    y_small = torch.empty(1000, 256, device="cuda", dtype=BF)
+    ops.rowgemm(x[:1000], W, y_small, 1000, 256, 256, bias=b, residual=res[:1000], ldr=256)
+    assert torch.equal(y_small, y[:1000])
+    # LayerNorm-fed qkv
+    Wq, g, bt, bq = rnd(768, 256, seed=6, scale=1 / 16), 1 + 0.3 * rnd(256, seed=7), 0.2 * rnd(256, seed=8), rnd(768, seed=9)
+    e = prep(ops, Wq, g, bt, bq)
+    yq, xhat, rstd = torch.empty(R, 768, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, device="cuda")
+    ops.rowgemm(x, e["Wp"], yq, R, 768, 256, bias=e["bp"], ln=True, xhat=xhat, rstd=rstd, stream_out=True)
+    xd = x[idx].double()
+    check(yq[idx], F.layer_norm(xd, (256,), g.double(), bt.double(), 1e-5) @ Wq.double().T + bq.double(), 6e-3, "full-size LN+qkv")
+    check(xhat[idx], F.layer_norm(xd, (256,), None, None, 1e-5), 3e-3, "full-size x_hat")
+    # its backward: dx = dres + LayerNorm'(dqkv . Wp)
+    dy = rnd(R, 768, seed=10, scale=0.5).to(BF)
+    dx = torch.empty(R, 256, device="cuda", dtype=BF)
+    ops.rowgemm(dy, e["WpT"], dx, R, 256, 768, ldw=768, residual=res, ldr=256, ln_bwd=True, bwd_xhat=xhat, bwd_rstd=rstd)
+    v, xh, rs = dy[idx].double() @ e["Wp"].double(), xhat[idx].double(), rstd[idx].double()[:, None]
+    check(dx[idx], res[idx].double() + rs * (v - v.mean(1, keepdim=True) - xh * (v * xh).mean(1, keepdim=True)), 5e-3, "full-size dX + LN backward")
+
+
+def test_full_size_mlp_forward_backward(ops):
+    R = R_FULL
+    idx = sample_rows(R, seed=1)
+    x, Wu, bu, Wd, bd, g, bt, up, dn = mlp_setup(ops, R, seed=60)
+    y, xhat, rstd = torch.full((R + 2, 256), 3.0, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, device="cuda")
+    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd, rotate=1))
+    assert torch.all(y[R:] == 3.0)
+    xd = x[idx].double().requires_grad_(True)
+    h = F.layer_norm(xd, (256,), g.double(), bt.double(), 1e-5)
+    u = h @ Wu.double().T + bu.double()
+    gl = F.gelu(u)
+    out = xd + gl @ Wd.double().T + bd.double()
+    check(y[idx], out.detach(), 6e-3, "full-size mlp fwd")
+    ys = torch.empty(1000, 256, device="cuda", dtype=BF)
+    ops.mlp_fwd(ops.mlp_desc(1000, x=x[:1000], w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=ys, xhat=torch.empty(1000, 256, device="cuda", dtype=BF),
+                             rstd=torch.empty(1000, device="cuda")))
+    assert torch.equal(ys, y[:1000])
+    dy = rnd(R, 256, seed=77).to(BF)
+    t1, gg, du, dx = (torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 512, device="cuda", dtype=BF),
+                      torch.empty(R, 512, device="cuda", dtype=BF), torch.full((R + 1, 256), 5.0, device="cuda", dtype=BF))
+    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpT"], t1=t1, g=gg, du=du, dx=dx, rotate=1))
+    assert torch.equal(t1, dy) and torch.all(dx[R:] == 5.0)
+    u.retain_grad(); gl.retain_grad()
+    out.backward(dy[idx].double())
+    check(gg[idx], gl.detach(), 6e-3, "full-size g")
+    check(du[idx], u.grad, 1.2e-2, "full-size du")
+    check(dx[idx], xd.grad, 1.2e-2, "full-size dx")
