@@ -641,3 +641,44 @@ def test_gemm_bf16_full_size_many_tiles_per_workgroup(ops, M, N, K, kc):
     else:
         ops.gemm(x[:1024], w, ys, 1024, N, K, lda=K, ldb=N, ldc=N, b_kcontig=0)
     assert torch.equal(ys, y[:1024])
+
+
+def test_attention_bf16_full_batch_matches_small_launches(ops):
+    """BASELINE configs[1] batch (B = 1024, 8 heads, L = 200, dh = 32): 8,192 workgroups in the XCD-aware (batch, head) order.  Without
+    dropout a head's result does not depend on where it sits in the batch: samples from the start, middle and end of the batch must
+    equal, bit for bit, a launch over those samples alone (forward output, LSE and all three gradients), and sample 0 is also
+    checked against the fp32 reference."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    B, heads, L, dh = 1024, 8, 200, 32
+    H = heads * dh
+    qkv, d_o = bf(rnd(B * L, 3 * H, seed=1)), bf(rnd(B * L, H, seed=2))
+    keypad = torch.ones(B, L, dtype=torch.uint8)
+    keypad[0, L - 3:] = 0
+    keypad[B - 1, 5:9] = 0
+    kp, mi = keypad.cuda(), (torch.arange(L) >= L // 2).to(torch.uint8).cuda()
+    scale, es = 1.0 / math.sqrt(dh), 2
+
+    def run(qkv_, d_o_, kp_, nb):
+        o, lse = torch.empty(nb * L, H, device="cuda", dtype=torch.bfloat16), torch.empty(nb, heads, L, device="cuda")
+        dqkv = torch.full((nb * L, 3 * H), float("nan"), device="cuda", dtype=torch.bfloat16)
+        base = qkv_.data_ptr()
+        desc = ops.attn_desc(Lb.BF16, nb, heads, L, L, dh, base, base + H * es, base + 2 * H * es, 3 * H, 3 * H, 3 * H, o.data_ptr(), H, lse, kp_, mi,
+                             1, scale, d_o=d_o_.data_ptr(), lddo=H, dq=dqkv.data_ptr(), dk=dqkv.data_ptr() + H * es,
+                             dv=dqkv.data_ptr() + 2 * H * es, lddq=3 * H, lddk=3 * H, lddv=3 * H)
+        ops.attn_fwd(desc)
+        ops.attn_bwd(desc)
+        torch.cuda.synchronize()
+        return o, lse, dqkv
+
+    o, lse, dqkv = run(qkv, d_o, kp, B)
+    for b0 in (0, 511, B - 2):
+        rows = slice(b0 * L, (b0 + 2) * L)
+        o2, lse2, dq2 = run(qkv[rows].contiguous(), d_o[rows].contiguous(), kp[b0:b0 + 2].contiguous(), 2)
+        assert torch.equal(o[rows], o2) and torch.equal(lse[b0:b0 + 2], lse2) and torch.equal(dqkv[rows], dq2), f"samples {b0}, {b0 + 1}"
+    x = qkv[:L].float().requires_grad_(True)
+    q, k, v = [t.view(1, L, heads, dh).transpose(1, 2) for t in x.split(H, dim=1)]
+    m = kp[:1].bool()[:, None, :].expand(1, L, L) | torch.eye(L, dtype=torch.bool, device="cuda")[None]
+    oref = ref_attention(q, k, v, m, scale).transpose(1, 2).reshape(L, H)
+    close_bf16(o[:L], oref, "bf16 attn fwd, sample 0 of 1024", tol=2e-2)
+    oref.backward(d_o[:L].float())
+    close_bf16(dqkv[:L], x.grad, "bf16 attn grads, sample 0 of 1024", tol=3e-2)
