@@ -445,12 +445,14 @@ def test_shape_pool_eviction_drops_plans(monkeypatch):
     assert len(eng._pools) == 2 and all((k[0], k[1]) in eng._pools for k in eng.plans)
 
 
-def test_bf16_fused_row_owner_path_matches_unfused_kernels(monkeypatch):
+@pytest.mark.parametrize("B", [16, 1024])
+def test_bf16_fused_row_owner_path_matches_unfused_kernels(monkeypatch, B):
     """bf16 mode, default widths: the row-owner fused kernels (LN folded into the linears, one-launch MLP with recompute,
     LN backward in the dX epilogues, LN / linear gradients from G = dY^T x_hat) against the un-fused round-1 kernels on the
-    same inputs: same loss to bf16 accuracy, same gradient direction for every tensor, and close to the fp32 reference."""
+    same inputs: same loss to bf16 accuracy, same gradient direction for every tensor, and close to the fp32 reference.
+    B = 1024 is the bench's batch (R = 204,800 rows: several 128-row passes per workgroup, persistent GEMM tiles)."""
     g = load_json("default_scalars.json")
-    batch = O.synth_batch(16, 100, 668, 2, seed=0)
+    batch = O.synth_batch(B, 100, 668, 2, seed=0)
     res = {}
     for mode in ("0", "15"):
         monkeypatch.setenv("MMFM_FUSED", mode)
@@ -464,12 +466,16 @@ def test_bf16_fused_row_owner_path_matches_unfused_kernels(monkeypatch):
             o = model(to_dev(O.make_mod_dict(batch, obj)))
             o.loss.backward()
             out[obj] = (o.loss.item(), {k: p.grad.detach().clone() for k, p in model.named_parameters()})
-        assert model._engine._fused_mask(16 * 200) == int(mode)          # (the env override also lifts the small-batch guard)
+        assert model._engine._fused_mask(B * 200) == int(mode)          # (the env override also lifts the small-batch guard)
         res[mode] = out
+        del model
+        torch.cuda.empty_cache()
     for obj in ("encoding", "token_masking"):
         l0, g0 = res["0"][obj]
         l1, g1 = res["15"][obj]
-        assert l1 == pytest.approx(l0, rel=3e-3) and l1 == pytest.approx(g[obj]["loss"], rel=2e-2)
+        assert l1 == pytest.approx(l0, rel=3e-3)
+        if B == 16:
+            assert l1 == pytest.approx(g[obj]["loss"], rel=2e-2)          # the fixture is the reference's loss on this very batch
         for k in g0:
             if g0[k].abs().max() == 0:
                 assert g1[k].abs().max() == 0, k
