@@ -303,8 +303,9 @@ class Engine:
         c = self.cfg
         if self.dtype != "bf16" or c.hidden != 256 or c.inter != 512 or (R + 128) * 1024 * 2 >= 2 ** 31:
             return 0
-        if R < 16384 and "MMFM_FUSED" not in os.environ:
-            return 0             # a row-owner pass is 128 rows: below ~64 passes per launch the grid cannot fill 256 CUs (B=16: 5.04 vs 4.97 ms)
+        if R < 12288 and "MMFM_FUSED" not in os.environ:
+            return 0             # a row-owner pass is 128 rows: below ~100 passes per launch the grid cannot fill 256 CUs
+                                 # (measured, un-fused vs fused ms/step: B=16 4.80 / 5.00, B=32 5.24 / 5.32, B=64 6.31 / 6.21, B=128 8.55 / 7.66)
         return int(os.environ.get("MMFM_FUSED", "15")) & 15        # default: everything fused, the fastest end to end (35.6 vs 36.3 ms)
 
     def _build_prep(self):

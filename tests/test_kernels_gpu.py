@@ -682,3 +682,58 @@ def test_attention_bf16_full_batch_matches_small_launches(ops):
     close_bf16(o[:L], oref, "bf16 attn fwd, sample 0 of 1024", tol=2e-2)
     oref.backward(d_o[:L].float())
     close_bf16(dqkv[:L], x.grad, "bf16 attn grads, sample 0 of 1024", tol=3e-2)
+
+
+def test_dropout_pair_hash_statistics(ops):
+    """The element dropout mask (one hash per PAIR of neighbouring elements, 16 bits each): keep rate within 4 sigma of 1 - p, no
+    correlation between the two elements of a pair, between neighbouring pairs, between rows, between sites or between steps
+    (|corr| < 0.01 on 4 M elements, noise 5e-4)."""
+    M, N, p = 4096, 1024, 0.4
+    x = torch.ones(M, N, device="cuda", dtype=torch.bfloat16)
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 1234)
+
+    def mask(site):
+        y = torch.empty_like(x)
+        ops.dropout_apply(x, y, M, N, ops.dropout(state, site, p))
+        return (y != 0).float()
+
+    k = mask(3)
+    assert abs(k.mean().item() - (1 - p)) < 4 * math.sqrt(p * (1 - p) / (M * N))
+    c = k - (1 - p)
+    var = p * (1 - p)
+    corr = lambda a, b: (a * b).mean().item() / var
+    assert abs(corr(c[:, 0::2], c[:, 1::2])) < 0.01                      # the two halves of one hash
+    for lag in (1, 2, 3, 4, 8, 16, 32, 64):
+        assert abs(corr(c[:, :-lag], c[:, lag:])) < 0.01, f"column lag {lag}"
+    for lag in (1, 2, 8):
+        assert abs(corr(c[:-lag], c[lag:])) < 0.01, f"row lag {lag}"
+    assert abs(corr(c, mask(4) - (1 - p))) < 0.01                        # another site
+    assert torch.equal(k, mask(3))                                       # same state, same site: same mask
+    ops.rng_advance(state)
+    assert abs(corr(c, mask(3) - (1 - p))) < 0.01                        # next step
+
+
+def test_gemm_bf16_gelu_polynomial_accuracy(ops):
+    """The bf16 kernels' GELU (packed degree-9 polynomial Phi, common.h phi2) and its derivative through the GEMM epilogues with an
+    identity weight: |gelu error| <= 1 bf16 ulp of the result + 5e-5 on [-4, 4], and |x| * 4e-5 beyond (Phi saturates at 1 - 3e-5)."""
+    n = 256
+    xs = torch.linspace(-9.0, 9.0, 64 * n, device="cuda").view(64, n)
+    x = bf(xs)
+    eye = torch.eye(n, device="cuda", dtype=torch.bfloat16)
+    y = torch.empty(64, n, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(x, eye, y, 64, n, n, lda=n, ldb=n, ldc=n, act=1)
+    xd = x.double()
+    ref = torch.nn.functional.gelu(xd)
+    err = (y.double() - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 5e-5 + xd.abs() * 4e-5
+    assert torch.all(err <= bound), f"gelu: worst excess {(err - bound).max().item():.3e} at x = {xd.flatten()[(err - bound).argmax()].item():.4f}"
+    # derivative: dx = dy * gelu'(pre) with dy = 1 (K = n identity product of ones-rows is the row sum: use dy = e_j rows instead)
+    dy = torch.eye(n, device="cuda", dtype=torch.bfloat16)[:64].contiguous()          # row i = e_i  ->  (dy @ I)[i, j] = delta_ij
+    pre = bf(torch.linspace(-9.0, 9.0, 64, device="cuda")[:, None].expand(64, n).contiguous())
+    dx = torch.empty(64, n, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(dy, eye, dx, 64, n, n, lda=n, ldb=n, ldc=n, b_kcontig=0, act=3, gradmul_pre=pre)
+    p64 = pre.double()[:, 0].clone().requires_grad_(True)
+    torch.nn.functional.gelu(p64).sum().backward()
+    got = dx.double()[torch.arange(64), torch.arange(64)]
+    assert torch.all((got - p64.grad).abs() <= p64.grad.abs() * 2.0 ** -8 + 1e-4), f"gelu': {(got - p64.grad).abs().max().item():.3e}"
