@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
         opnd x[16];
         load_rows_lines<4>(stg, x, X, wrow0, ldxb, lane, m, h);
         const float rs = ln_rows(x, d.eps);
-        store_rows_lines<4, false>(stg, XH, wrow0, 512u, lane, m, h, x);
+        store_rows_lines<4, true>(stg, XH, wrow0, 512u, lane, m, h, x);
         st4f(RS, h == 0 ? row * 4u : 0xfffffff0u, rs);
         f32x16 Y8[8];
 #pragma unroll
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
         opnd x[16];
         load_rows_lines<4>(stg, x, X, wrow0, ldxb, lane, m, h);
         const float rs = ln_rows(x, d.eps);
-        store_rows_lines<4, false>(stg, XH, wrow0, 512u, lane, m, h, x);       // role 1: zero-sized buffer, dropped
+        store_rows_lines<4, true>(stg, XH, wrow0, 512u, lane, m, h, x);       // role 1: zero-sized buffer, dropped
         st4f(RS, h == 0 ? row * 4u : 0xfffffff0u, rs);
         f32x16 Yh[4];
 #pragma unroll

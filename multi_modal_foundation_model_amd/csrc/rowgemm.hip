@@ -58,7 +58,7 @@ __global__ __launch_bounds__(NWV * 64, (KP == 1 ? 2 : 1)) void rowgemm_kernel(co
         if (live) load_rows_lines<4 * KP>(stg, x, X, wrow0, ldxb, lane, m, h);
         if constexpr (LN) if (live) {
             const float rs = ln_rows(x, d.eps);
-            store_rows_lines<4, false>(stg, XH, wrow0, 512u, lane, m, h, x);
+            store_rows_lines<4, true>(stg, XH, wrow0, 512u, lane, m, h, x);
             st4f(RS, h == 0 ? (wrow0 + m) * 4u : 0xfffffff0u, rs);
         }
         for (int tp = 0; tp < npair; ++tp) {
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) void rowgemm8_kernel(const mmfm_rowgemm_desc d
         if (live) load_rows_lines<4>(stg, x, X, wrow0, ldxb, lane, m, h);
         if constexpr (LN) if (live) {
             const float rs = ln_rows(x, d.eps);
-            store_rows_lines<4, false>(stg, XH, wrow0, 512u, lane, m, h, x);
+            store_rows_lines<4, true>(stg, XH, wrow0, 512u, lane, m, h, x);
             st4f(RS, h == 0 ? (wrow0 + m) * 4u : 0xfffffff0u, rs);
         }
         f32x16 acc[2];                                    // late group: holds the previous step's tile pair until its epilogue
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512) void rowgemm7_kernel(const mmfm_rowgemm_desc d
         }
         if constexpr (LN) {
             const float rs = ln_rows(x, d.eps);
-            store_rows_lines<4, false>(stg, XH, wrow0, 512u, lane, m, h, x);
+            store_rows_lines<4, true>(stg, XH, wrow0, 512u, lane, m, h, x);
             st4f(RS, h == 0 ? (wrow0 + m) * 4u : 0xfffffff0u, rs);
         }
         Lines res;
