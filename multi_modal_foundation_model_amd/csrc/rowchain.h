@@ -512,11 +512,15 @@ __device__ __forceinline__ void flush_lines(const char* stg, const GBuf& b, uint
     }
 }
 // global -> staging (whole lines), for later reads in either layout
+#ifndef MMFM_ACT_LOAD_AUX
+#define MMFM_ACT_LOAD_AUX 0
+#endif
 struct Lines { uint4 v[4]; };
 __device__ __forceinline__ Lines fetch_lines(const GBuf& b, uint32_t wrow0, uint32_t ldb, uint32_t colb, int lane) {
     Lines L;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) L.v[i] = ld16(b, (wrow0 + 8 * i + (lane >> 3)) * ldb + colb + 16 * (lane & 7));
+    for (int i = 0; i < 4; ++i)
+        L.v[i] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(b.rs, (int)((wrow0 + 8 * i + (lane >> 3)) * ldb + colb + 16 * (lane & 7)), 0, MMFM_ACT_LOAD_AUX));
     return L;
 }
 __device__ __forceinline__ void stage_lines(char* stg, const Lines& L, int lane) {
