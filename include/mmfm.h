@@ -90,6 +90,17 @@ int mmfm_gemm(const mmfm_gemm_desc* d, mmfm_stream stream);
  * clobbered (a tall-skinny reduction first sums groups of slabs in place). */
 int mmfm_reduce_slabs(float* dst, const float* src, int64_t n, int nslabs, int64_t slab_stride,
                       int accumulate, mmfm_stream stream);
+/* Several slab reductions in ONE launch (small batches: a backward segment's weight-gradient GEMMs each leave a few small
+ * slabs, and a launch per reduction costs more than the reduction).  `table` is a DEVICE array of `count` entries; every entry
+ * keeps its own slab region until the call.  chunk0 = number of 256-float chunks of the entries before it (exclusive prefix sum of
+ * ceil(n / 256)); `total_chunks` = that sum over all entries.  Deterministic slab order, like mmfm_reduce_slabs. */
+typedef struct {
+    float* dst;
+    const float* src;
+    int64_t n, slab_stride;
+    int32_t nslabs, accumulate, chunk0, pad_;
+} mmfm_reduce_entry;
+int mmfm_reduce_slabs_multi(const mmfm_reduce_entry* table, int count, int total_chunks, mmfm_stream stream);
 /* out[n] (+)= sum_r x[r*ld + n]   (bias gradients).  workspace >= mmfm_colsum_workspace bytes. */
 int64_t mmfm_colsum_workspace(int64_t R, int N);
 int mmfm_colsum(int dtype, const void* x, int64_t R, int N, int ld, float* out, int accumulate,

@@ -57,6 +57,11 @@ class PrepEntry(C.Structure):
                 ("WpT", C.c_void_p), ("bp", C.c_void_p), ("N", C.c_int), ("K", C.c_int), ("tile0", C.c_int), ("pad_", C.c_int)]
 
 
+class ReduceEntry(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("n", C.c_int64), ("slab_stride", C.c_int64), ("nslabs", C.c_int32),
+                ("accumulate", C.c_int32), ("chunk0", C.c_int32), ("pad_", C.c_int32)]
+
+
 class RowGemmDesc(C.Structure):
     _fields_ = [("R", C.c_int64), ("K", C.c_int), ("N", C.c_int), ("x", C.c_void_p), ("ldx", C.c_int), ("w", C.c_void_p),
                 ("ldw", C.c_int), ("bias", C.c_void_p), ("ln", C.c_int), ("eps", C.c_float), ("xhat", C.c_void_p),
@@ -81,6 +86,7 @@ _PROTOS = {
     "mmfm_rng_advance": (C.c_int, [_vp, _vp]),
     "mmfm_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
     "mmfm_reduce_slabs": (C.c_int, [_vp, _vp, _i64, _i, _i64, _i, _vp]),
+    "mmfm_reduce_slabs_multi": (C.c_int, [_vp, _i, _i, _vp]),
     "mmfm_colsum_workspace": (C.c_int64, [_i64, _i]),
     "mmfm_colsum": (C.c_int, [_i, _vp, _i64, _i, _i, _vp, _i, _vp, _i64, _vp]),
     "mmfm_layernorm_fwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp]),

@@ -334,6 +334,30 @@ extern "C" int mmfm_gemm(const mmfm_gemm_desc* dp, mmfm_stream stream) {
     return 0;
 }
 
+// Several reductions in one launch: block b owns one 256-float chunk of one entry (found by bisection over the entries' chunk0
+// prefix sums, <= 7 steps for the ~70 entries of a backward segment).
+__global__ __launch_bounds__(256) void reduce_slabs_multi_kernel(const mmfm_reduce_entry* __restrict__ tab, int count) {
+    int lo = 0, hi = count - 1;
+    const int b = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].chunk0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const mmfm_reduce_entry e = tab[lo];
+    const int64_t i = (int64_t)(b - e.chunk0) * 256 + threadIdx.x;
+    if (i >= e.n) return;
+    float s = e.accumulate ? e.dst[i] : 0.f;
+    for (int k = 0; k < e.nslabs; ++k) s += e.src[(size_t)k * e.slab_stride + i];
+    e.dst[i] = s;
+}
+
+extern "C" int mmfm_reduce_slabs_multi(const mmfm_reduce_entry* table, int count, int total_chunks, mmfm_stream stream) {
+    MMFM_REQUIRE(table && count > 0 && total_chunks > 0, "mmfm_reduce_slabs_multi: bad arguments");
+    hipLaunchKernelGGL(reduce_slabs_multi_kernel, dim3(total_chunks), dim3(256), 0, (hipStream_t)stream, table, count);
+    MMFM_LAUNCH_CHECK("mmfm_reduce_slabs_multi");
+    return 0;
+}
+
 // NOTE: `src` is scratch and may be clobbered (the two-stage path sums each slab group into its first slab).
 extern "C" int mmfm_reduce_slabs(float* dst, const float* src_c, int64_t n, int nslabs, int64_t slab_stride,
                                  int accumulate, mmfm_stream stream) {

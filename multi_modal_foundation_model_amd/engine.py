@@ -399,6 +399,20 @@ class Engine:
             S, _ = self._dw_split(mm, nn, R)
             max_slab = max(max_slab, S * _align(mm * nn + mm))
         slab = buf("ws/slab", (max_slab,), f32)
+        # launch-bound regime (R <= 8192, the reference's batch of 16): every dW GEMM keeps its own slab region and ONE
+        # mmfm_reduce_slabs_multi per backward segment sums them all (66 reductions of ~7 us each otherwise)
+        batch_red = R <= 8192 and os.environ.get("MMFM_BATCH_REDUCE", "1") != "0"
+        pend: list = []
+        slabm_off = [0]
+        if batch_red:
+            s_max = max(1, min(R // 256, 15))
+            slabm = buf("ws/slabm", (s_max * (self.layout.n + 128 * 64),), f32)
+
+        def slab_region(S, stride):
+            o = slabm_off[0]
+            slabm_off[0] = o + S * stride
+            assert slabm_off[0] <= slabm.numel(), "ws/slabm too small"
+            return slabm[o:o + S * stride]
         maxN = max([3 * H, I] + [n * c.mult for _, n in c.mods])
         ws_col = buf("ws/col", (max(1, L.lib().mmfm_colsum_workspace(R, maxN) // 4),), f32)
         ws_ln = buf("ws/ln", (max(1, L.lib().mmfm_layernorm_bwd_workspace(R, H) // 4),), f32)
@@ -422,13 +436,21 @@ class Engine:
                        colsum=gb if fused else None, plan=plan)
             elif adjacent:
                 stride = _align(N * Kd + N)
-                K.gemm(dY, X, slab, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
-                       slab_stride=stride, dtype=code, c_f32=1, colsum=slab.data_ptr() + 4 * N * Kd, plan=plan)
-                K.reduce_slabs(gw, slab, N * Kd + N, S, stride, plan=plan)
+                sl = slab_region(S, stride) if batch_red else slab
+                K.gemm(dY, X, sl, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
+                       slab_stride=stride, dtype=code, c_f32=1, colsum=sl.data_ptr() + 4 * N * Kd, plan=plan)
+                if batch_red:
+                    pend.append((gw, sl, N * Kd + N, S, stride, False))
+                else:
+                    K.reduce_slabs(gw, sl, N * Kd + N, S, stride, plan=plan)
             else:
-                K.gemm(dY, X, slab, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
+                sl = slab_region(S, N * Kd) if batch_red else slab
+                K.gemm(dY, X, sl, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
                        slab_stride=N * Kd, dtype=code, c_f32=1, plan=plan)
-                K.reduce_slabs(gw, slab, N * Kd, S, N * Kd, plan=plan)
+                if batch_red:
+                    pend.append((gw, sl, N * Kd, S, N * Kd, False))
+                else:
+                    K.reduce_slabs(gw, sl, N * Kd, S, N * Kd, plan=plan)
             if not fused or (S > 1 and not adjacent):
                 K.colsum(dY, Mr, N, N, gb, ws_col, plan=plan)
             if dX is not None:
@@ -600,6 +622,9 @@ class Engine:
 
         def close_segment(name):
             nonlocal cur
+            if pend:                          # the segment's weight-gradient slabs, all in one launch, before its DDP hook fires
+                K.reduce_slabs_multi(list(pend), self.device, plan=cur)
+                pend.clear()
             bwd.append((name, cur))
             cur = []
 

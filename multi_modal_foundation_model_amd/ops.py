@@ -69,6 +69,19 @@ def reduce_slabs(dst, src, n, nslabs, stride, accumulate=False, plan=None):
     _emit(plan, L.lib().mmfm_reduce_slabs, (P(dst), P(src), n, nslabs, stride, int(accumulate)))
 
 
+def reduce_slabs_multi(items, device, plan=None):
+    """items: (dst tensor, slab tensor, n, nslabs, stride, accumulate) -> one launch (mmfm_reduce_slabs_multi).  The table tensor
+    is kept alive by the plan entry."""
+    import numpy as np
+    arr = (L.ReduceEntry * len(items))()
+    chunk0 = 0
+    for a, (dst, src, n, nslabs, stride, acc) in zip(arr, items):
+        a.dst, a.src, a.n, a.slab_stride, a.nslabs, a.accumulate, a.chunk0 = P(dst), P(src), n, stride, nslabs, int(acc), chunk0
+        chunk0 += (n + 255) // 256
+    table = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)
+    _emit(plan, L.lib().mmfm_reduce_slabs_multi, (P(table), len(items), chunk0), keep=(table,))
+
+
 def colsum(x, R, N, ld, out, ws, accumulate=False, plan=None):
     _emit(plan, L.lib().mmfm_colsum, (dt(x), P(x), R, N, ld, P(out), int(accumulate), P(ws), ws.numel() * ws.element_size()))
 

@@ -737,3 +737,18 @@ def test_gemm_bf16_gelu_polynomial_accuracy(ops):
     torch.nn.functional.gelu(p64).sum().backward()
     got = dx.double()[torch.arange(64), torch.arange(64)]
     assert torch.all((got - p64.grad).abs() <= p64.grad.abs() * 2.0 ** -8 + 1e-4), f"gelu': {(got - p64.grad).abs().max().item():.3e}"
+
+
+def test_reduce_slabs_multi_matches_single_reductions(ops):
+    """mmfm_reduce_slabs_multi: several slab reductions (ragged sizes, different slab counts, one accumulating) in one launch."""
+    specs = [(1000, 3, False), (256, 1, False), (77, 15, True), (4096 + 5, 7, False), (1, 2, False)]
+    items, refs = [], []
+    for i, (n, S, acc) in enumerate(specs):
+        stride = (n + 7) // 8 * 8
+        src = rnd(S, stride, seed=10 + i)
+        dst = rnd(n, seed=50 + i)
+        refs.append((dst.double() if acc else 0) + src[:, :n].double().sum(0))
+        items.append((dst, src, n, S, stride, acc))
+    ops.reduce_slabs_multi(items, "cuda")
+    for (dst, *_), ref in zip(items, refs):
+        close(dst, ref, rtol=1e-5, atol=1e-5, msg="reduce_slabs_multi")
