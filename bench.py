@@ -180,7 +180,7 @@ def leg_trainer(dev, dtype, B, exact_masker, sessions=None, steps=8, warm=3):
     model = build_model(cfg.model, 668, 2, seed=cfg.seed)
     model.compute_dtype = dtype
     model.engine_seed = 99
-    model.masker.token_mask_only = not exact_masker
+    cfg["training"]["exact_masker_stream"] = bool(exact_masker)      # default trainer behaviour: token-mask-only stream (trainer/base.py)
     model = model.to(dev).train()
     opt = make_optimizer(model, lr=cfg.optimizer.lr, weight_decay=cfg.optimizer.wd, eps=cfg.optimizer.eps)
     sch = OneCycleLR(optimizer=opt, total_steps=1000, max_lr=cfg.optimizer.lr, pct_start=cfg.optimizer.warmup_pct, div_factor=cfg.optimizer.div_factor)
@@ -290,8 +290,7 @@ def main():
     model = build_model(cfg.model, n_ap, n_beh, seed=cfg.seed)          # same init on every rank (set_seed(42) upstream)
     model.compute_dtype = a.dtype
     model.engine_seed = 1234 + rank
-    model.masker.token_mask_only = True     # the [B,T,N] corruption draws are dead work in the embd path
-    model = model.to(dev)
+    model = model.to(dev)       # the trainer (default config) switches the masker to its token-mask-only host stream (trainer/base.py)
     if world > 1:
         model = DataParallelModel(model)
     total = max(1000, a.steps + a.warmup + 1)
@@ -366,7 +365,9 @@ def main():
                    model_tflops_per_gpu=round(fl_step / (dt / a.steps) / 1e12, 2),
                    frac_of_mfma_peak_whole_step=round(fl_step / (dt / a.steps) / 1e12 / PEAK_TFLOPS[a.dtype], 4))
         res["inputs"] = "host (pinned), PCIe inside the timed region" if a.host_inputs else "resident in HBM"
-        res["masker_token_mask_only"] = True     # `value` skips the three dead [B,T,N] corruption draws of the embd path
+        # the trainer's DEFAULT for mask_type 'embd' (trainer/base.py): token-mask-only host stream; `value_exact_masker` below is the
+        # same step under training.exact_masker_stream (the reference's CPU generator walk, host-bound)
+        res["masker_token_mask_only"] = bool(getattr(model.masker, "token_mask_only", False))
         res["fused_mask"] = eng._fused_mask(B * 200)
         log(f"{ms:.2f} ms/step, {value:.1f} samples/s")
         if not a.no_kernel_profile:

@@ -832,6 +832,7 @@ int check_common(const mmfm_attn_desc& d, const char* who) {
     }
 
 int mmfm_attn_bf16_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st);   // attention_bf16.hip (bf16 MFMA)
+int mmfm_attn_fast_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st);   // attention_fast.hip (bf16, dh 32, L <= 224)
 
 #define ATTN_TILED(KERN, GY, ...)                                                                                  \
     {                                                                                                              \
@@ -872,6 +873,8 @@ extern "C" int mmfm_attn_fwd(const mmfm_attn_desc* dp, mmfm_stream stream) {
     const mmfm_attn_desc d = d_;
     if (int rc = check_common(d, "mmfm_attn_fwd")) return rc;
     if (d.dtype == MMFM_BF16) {          // bf16 MFMA kernel; shapes it does not take fall through to fp32 compute on bf16 storage
+        const int rf = mmfm_attn_fast_launch(d, false, (hipStream_t)stream);
+        if (rf != -1000) return rf;
         const int rc = mmfm_attn_bf16_launch(d, false, (hipStream_t)stream);
         if (rc != -1000) return rc;
     }
@@ -901,6 +904,8 @@ extern "C" int mmfm_attn_bwd(const mmfm_attn_desc* dp, mmfm_stream stream) {
     MMFM_REQUIRE(d.lddo >= hd && d.lddq >= hd && d.lddk >= hd && d.lddv >= hd, "mmfm_attn_bwd: gradient leading dim < heads*dh");
     MMFM_REQUIRE(d.lddo % 4 == 0 && d.lddq % 4 == 0 && d.lddk % 4 == 0 && d.lddv % 4 == 0, "mmfm_attn_bwd: gradient leading dims must be multiples of 4");
     if (d.dtype == MMFM_BF16) {
+        const int rf = mmfm_attn_fast_launch(d, true, (hipStream_t)stream);
+        if (rf != -1000) return rf;
         const int rc = mmfm_attn_bf16_launch(d, true, (hipStream_t)stream);
         if (rc != -1000) return rc;
     }

@@ -11,44 +11,15 @@
 //   forward : S^T = K Q^T  ->  online softmax (lane = query)  ->  O^T += V^T P^T
 //   backward: phase A (wave owns 32 keys):  S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS
 //             phase B (wave owns 32 queries): S^T, dP^T, dQ^T += K^T dS^T        (no atomics)
-#include "common.h"
+#include "attn_common.h"
 #include <algorithm>
 #include <stdlib.h>
 #include <mutex>
 #include <unordered_map>
 
+using namespace attn;
+
 namespace {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8v;
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-typedef __attribute__((ext_vector_type(8))) short s16x8;
-typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-
-constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-
-__device__ __forceinline__ int mrow(int r, int kh) { return (r & 3) + 8 * (r >> 2) + 4 * kh; }
-
-__device__ __forceinline__ bf16x8v pack8(const float* p) {
-    bf16x8v v;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (__bf16)p[j];
-    return v;
-}
-__device__ __forceinline__ bf16x8v rowfrag(const char* S, int byte) {
-    return __builtin_bit_cast(bf16x8v, *reinterpret_cast<const uint4*>(S + byte));
-}
-// Transposed operand from a row-major [row][col] bf16 image with RS-byte rows: lane (c = lane%32, h = lane/32)
-// gets element j = image[rbase + 8*(j>>2) + 4*h + (j&3)][cbase + c]   (the k order of an accumulator-fed MFMA).
-__device__ __forceinline__ bf16x8v trfrag(const char* S, int RS, int rbase, int cbase, int lane) {
-    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
-    const int row = rbase + 4 * (g >> 1) + q;
-    const int col = cbase + 16 * (g & 1) + 4 * p;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(S + row * RS + col * 2));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(S + (row + 8) * RS + col * 2));
-    s16x8 v;
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    return __builtin_bit_cast(bf16x8v, v);
-}
 
 struct MaskCtx {
     const uint8_t* kpad;
@@ -91,24 +62,6 @@ __device__ __forceinline__ Drop16 drop16_init(mmfm_dropout d) {
     Drop16 r;
     r.k0 = b.k0; r.k1 = b.k1; r.t16 = b.thresh >> 16; r.scale = b.scale; r.on = b.on();
     return r;
-}
-
-// rows [0,L) x DH bf16 of one head -> LDS image with RS-byte rows and CPR 16-B chunks per row; the rest zero
-template <int DH>
-__device__ __forceinline__ void load_head16(char* __restrict__ dst, int RS, int CPR, const uint16_t* __restrict__ src, int ld, int L, int LP,
-                                            int t, int nthreads) {
-    constexpr int C8 = DH / 8;
-    for (int idx = t; idx < LP * CPR; idx += nthreads) {
-        const int row = idx / CPR, c = idx % CPR;
-        uint4 v = make_uint4(0u, 0u, 0u, 0u);
-        if (row < L && c < C8) v = *reinterpret_cast<const uint4*>(src + (size_t)row * ld + 8 * c);
-        *reinterpret_cast<uint4*>(dst + row * RS + c * 16) = v;
-    }
-}
-
-__device__ __forceinline__ void wave_lds_fence() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
 }
 
 // ============================================================================ forward
@@ -405,35 +358,6 @@ __device__ __forceinline__ void bwdB_tile(const f32x16& s, const f32x16& dpv, fl
         }
         ds[r] = p0 * (g0 - dq_);
         ds[r + 1] = p1 * (g1 - dq_);
-    }
-}
-
-// Accumulator tile (rows = head dim d, lane = token) -> bf16 rows [token][d] written IN PLACE into the wave's own,
-// already consumed 32-row tile of an LDS image (RS-byte rows), then streamed to global as 16-B row chunks.
-template <int DH, int DT>
-__device__ __forceinline__ void store_tile_T(char* tile, int RS, const f32x16 (&acc)[DT], uint16_t* outg, int ld, int row0, int nrows_total,
-                                             int lane, float osc) {
-    const int l31 = lane & 31, kh = lane >> 5;
-    wave_lds_fence();
-#pragma unroll
-    for (int i = 0; i < DT; ++i)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int dcol = i * 32 + 8 * g + 4 * kh;
-            if (dcol < DH) {
-                typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4v;
-                bf16x4v v;
-                v[0] = (__bf16)(acc[i][4 * g + 0] * osc); v[1] = (__bf16)(acc[i][4 * g + 1] * osc);
-                v[2] = (__bf16)(acc[i][4 * g + 2] * osc); v[3] = (__bf16)(acc[i][4 * g + 3] * osc);
-                *reinterpret_cast<uint2*>(tile + l31 * RS + dcol * 2) = __builtin_bit_cast(uint2, v);
-            }
-        }
-    wave_lds_fence();
-    constexpr int C8 = DH / 8;
-    for (int idx = lane; idx < 32 * C8; idx += 64) {
-        const int row = idx / C8, c = idx % C8;
-        if (row0 + row < nrows_total)
-            *reinterpret_cast<uint4*>(outg + (size_t)(row0 + row) * ld + 8 * c) = *reinterpret_cast<const uint4*>(tile + row * RS + c * 16);
     }
 }
 

@@ -104,7 +104,9 @@ struct Drop {
     __device__ __forceinline__ uint32_t hash(uint32_t pidx) const {
         uint32_t h = pidx ^ k0;
         h ^= h >> 16;
-        h = __umul24(h, 0x7FEB35u) + k1;
+        // v_mul_u32_u24 sees bits 0..23 only: the top byte enters through its own multiply (an additive, non-cancelling term).
+        // Without it hash(p) == hash(p ^ (d << 24 | d << 8)) for every d: tensors beyond 2^25 elements repeated their masks.
+        h = __umul24(h, 0x7FEB35u) + (__umul24(h >> 24, 0x9E3779u) + k1);
         h ^= h >> 13;
         h = __umul24(h, 0x46CA6Bu) ^ (h >> 9);
         h ^= h >> 16;

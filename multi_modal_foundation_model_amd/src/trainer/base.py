@@ -99,6 +99,16 @@ class MultiModalTrainer():
         else:
             self.training_mode = None
         self.use_wandb = bool(self.config.wandb.use) and wandb is not None
+        # mask_type 'embd': the model keeps only the token-level mask of the masker and DISCARDS the corrupted spikes
+        # (mm.py:262-267), so the masker's three full-size [B, T, N] host draws are dead work (330 ms per step at B = 1024, ten GPU
+        # steps).  The trainer therefore switches the masker to its token-mask-only stream - identically distributed masks, a
+        # shorter walk through the host generator - unless `training.exact_masker_stream: true` (or MMFM_EXACT_MASKER=1) asks for
+        # the reference's exact generator stream, which the parity tests do.
+        masker = getattr(self.model, "masker", None)
+        exact = bool(self.config.training.get("exact_masker_stream", False)) if hasattr(self.config.training, "get") else False
+        exact = exact or os.environ.get("MMFM_EXACT_MASKER", "0") == "1"
+        if masker is not None and hasattr(masker, "token_mask_only") and self.config.training.mask_type == "embd" and not exact:
+            masker.token_mask_only = True
         # host-side constants of the batch -> mod_dict translation, built once instead of every step: the
         # modality-index scalars (a pageable H2D copy each = a stream drain per call) and the [B, N] region array
         self._mod_index_cache = {}

@@ -686,6 +686,68 @@ def fx_masker_modes():
     save_npz("masker_modes.npz", **arrs)
 
 
+def fx_masker_modes_model():
+    """f4 on the model path: every masker mode through the reference's MultiModal.forward / backward with eval_mask = None
+    (the model draws its own masks, mm.py:262-267 keeps channel 0 of the masker's mask), the mode set by mutating
+    `model.masker` AFTER construction as utils/eval_utils.py:63-67 does.  Stored: inputs, state dict, per-modality mask, exact n,
+    loss, predictions and every gradient norm.  A mode the reference cannot run on this two-modality batch is stored as
+    raises = <exception type name>."""
+    B, T, n_ap, n_beh = 3, 20, 9, 2
+    regions_row = ["CA1", "PO", "CA1", "LP", "PO", "CA1", "LP", "PO", "DG"]
+    cases_in = [
+        dict(mode="neuron", ratio=0.3),
+        dict(mode="random", ratio=0.2),
+        dict(mode="co-smooth", ratio=0.3, channels=[1]),
+        dict(mode="co-smooth", ratio=0.3, channels=[1, 4, 7]),
+        dict(mode="forward-pred", ratio=0.3, timesteps=[15, 16, 17, 18, 19]),
+        dict(mode="inter-region", ratio=0.3, mask_regions=["CA1", "PO", "LP"], target_regions=["all"], n_mask_regions=2),
+        dict(mode="intra-region", ratio=0.4, mask_regions=["all"], target_regions=["CA1", "PO"], n_mask_regions=1),
+        dict(mode="causal", ratio=0.3, max_timespan=3, causal_zero=True),
+        dict(mode="causal", ratio=0.3, max_timespan=2, causal_zero=False),
+        dict(mode="temporal", ratio=0.3, expand_prob=1.0, max_timespan=4),
+    ]
+    arrs, cases = {}, []
+    mcfg = tiny_model_cfg(max_F=T)
+    batch = synth_batch(B, T, n_ap, n_beh, seed=5, pad=[0, 3, 0])
+    for k, v in batch.items():
+        arrs[f"batch/{k}"] = npify(v)
+    regions = np.asarray([regions_row] * B)
+    for cid, kw in enumerate(cases_in):
+        model = build_model(mcfg, n_ap, n_beh, seed=9)
+        if cid == 0:
+            for k, v in model.state_dict().items():
+                arrs[f"sd/{k}"] = npify(v)
+        for k, v in kw.items():
+            setattr(model.masker, k, v)
+        model.train()
+        torch.manual_seed(31 + cid)
+        random.seed(41 + cid)
+        md = make_mod_dict(batch, "token_masking", regions=regions)
+        rec = dict(id=cid, set=kw)
+        try:
+            out = model(md)
+            out.loss.backward()
+        except Exception as e:  # noqa: BLE001 - the fixture records what upstream does
+            rec["raises"] = type(e).__name__
+            cases.append(rec)
+            continue
+        rec["raises"] = None
+        rec["loss"] = float(out.loss)
+        rec["n"] = {m: int(out.mod_n_examples[m]) for m in ("ap", "behavior")}
+        rec["mod_loss"] = {m: float(out.mod_loss[m]) for m in ("ap", "behavior")}
+        rec["grad_norm"] = {k: (0.0 if p.grad is None else float(p.grad.double().norm())) for k, p in model.named_parameters()}
+        rec["after_rand"] = float(torch.rand(1))
+        rec["after_random"] = random.random()
+        for m in ("ap", "behavior"):
+            arrs[f"c{cid}/mask/{m}"] = npify(md[m]["inputs_mask"])
+            arrs[f"c{cid}/preds/{m}"] = npify(out.mod_preds[m])
+        cases.append(rec)
+    arrs["meta"] = np.frombuffer(json.dumps(dict(B=B, T=T, n_ap=n_ap, n_beh=n_beh, regions=regions_row, model_seed=9, cases=cases)).encode(),
+                                 dtype=np.uint8)
+    save_npz("masker_modes_model.npz", **arrs)
+    print("   cases:", [(c["set"]["mode"], c["raises"]) for c in cases])
+
+
 def fx_loss_curve_1k_default():
     """The north star's curve at the metric's own config: d_model 256, 5+5 layers, T=100, 668+2 channels, B=16, dropout 0,
     1000 optimisation steps of the reference on the CPU (mixed objectives, OneCycleLR over the 1000 steps)."""
@@ -873,7 +935,7 @@ def main():
     for name, fn in [("init_order", fx_init_order), ("tiny_fwd_bwd", fx_tiny_fwd_bwd),
                      ("default_scalars", fx_default_scalars), ("masker_bits", fx_masker_bits),
                      ("mask_index_ops", fx_mask_index_ops), ("sched_adamw", fx_sched_adamw),
-                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("multisession_curve", fx_multisession_curve), ("eval_metrics", fx_eval_metrics), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate), ("masker_modes", fx_masker_modes), ("eval_driver", fx_eval_driver),
+                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("multisession_curve", fx_multisession_curve), ("eval_metrics", fx_eval_metrics), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate), ("masker_modes", fx_masker_modes), ("masker_modes_model", fx_masker_modes_model), ("eval_driver", fx_eval_driver),
                      ("h64_curve", fx_h64_curve), ("multisession_big", fx_multisession_big), ("loss_curve_1k_default", fx_loss_curve_1k_default)]:
         if only and name not in only:
             continue

@@ -617,6 +617,106 @@ def test_attention_bf16_dropout_consistency(ops, L, dh):
     close(dv.sum(1), o.float().view(B, L, heads, dh)[..., 0].sum(1), rtol=2e-2, atol=0.5, msg="bf16 fwd/bwd dropout mask agree")
 
 
+def _decode_dropmask(buf, B, heads, Lq, Lk):
+    """keep[b, h, q, k] out of the mmfm_attn_desc.drop_mask layout [b*heads][query tile][key tile][32 words]: word w of a tile is key
+    mrow(w >> 1, w & 1) = ((w>>1)&3) + 8*((w>>1)>>2) + 4*(w&1), bit i is query i of the tile (include/mmfm.h, csrc/attention_fast.hip)."""
+    nqt, nkt = (Lq + 31) // 32, (Lk + 31) // 32
+    wds = buf.view(B * heads, nqt, nkt, 32).to(torch.int64) & 0xFFFFFFFF
+    w = torch.arange(32, device=buf.device)
+    key_of_w = ((w >> 1) & 3) + 8 * ((w >> 1) >> 2) + 4 * (w & 1)
+    bits = (wds[..., None] >> torch.arange(32, device=buf.device)) & 1                 # [bh, qt, kt, w, i]
+    keep = torch.zeros(B * heads, nqt, nkt, 32, 32, dtype=torch.bool, device=buf.device)  # [bh, qt, kt, key_local, i]
+    keep[:, :, :, key_of_w, :] = bits.bool()
+    keep = keep.permute(0, 1, 4, 2, 3).reshape(B * heads, nqt * 32, nkt * 32)           # [bh, q, k]
+    return keep[:, :Lq, :Lk].reshape(B, heads, Lq, Lk)
+
+
+@pytest.mark.parametrize("B,heads,Lq,Lk,flags,pad", [(2, 8, 200, 200, 1, True), (2, 8, 200, 200, 0, False), (3, 4, 72, 40, 0, True), (2, 4, 224, 224, 1, False),
+                                                     (2, 2, 104, 104, 1, True)])
+def test_attention_fast_dropmask_matches_reference(ops, B, heads, Lq, Lk, flags, pad):
+    """The dh = 32 fast pair (csrc/attention_fast.hip) with attention-probability dropout drawn from the precomputed keep mask: the
+    forward fills drop_mask, the test decodes it and evaluates softmax -> mask / (1 - p) -> P.V in torch fp32 on the same bf16 inputs;
+    output, LSE and all three gradients must match.  Keys 150.. carry 6x larger rows so that the running maximum jumps late in the
+    key sweep by more than the lazy-rescale threshold (cdna_hip_programming.md rule 26: force the rare branch)."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    dh, p = 32, 0.4
+    H = heads * dh
+    q = bf(rnd(B * Lq, H, seed=1))
+    kv = rnd(B * Lk, 2 * H, seed=2)
+    kv.view(B, Lk, 2 * H)[:, (3 * Lk) // 4:, :H] *= 6.0
+    kv = bf(kv)
+    d_o = bf(rnd(B * Lq, H, seed=3))
+    kp = torch.ones(B, Lk, dtype=torch.uint8)
+    if pad:
+        kp[0, Lk - 3:] = 0
+        kp[B - 1, 5:9] = 0
+    kp = kp.cuda()
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 4321)
+    dmask = torch.zeros(ops.attn_dropmask_bytes(B, heads, Lq, Lk) // 4, dtype=torch.int32, device="cuda")
+    o, lse = torch.empty(B * Lq, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, Lq, device="cuda")
+    dq, dkv = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
+    desc = ops.attn_desc(Lb.BF16, B, heads, Lq, Lk, dh, q.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * 2, H, 2 * H, 2 * H, o.data_ptr(), H, lse,
+                         kp, None, flags, dh ** -0.5, drop_p=ops.dropout(state, 7, p), d_o=d_o.data_ptr(), lddo=H, dq=dq.data_ptr(),
+                         dk=dkv.data_ptr(), dv=dkv.data_ptr() + H * 2, lddq=H, lddk=2 * H, lddv=2 * H, drop_mask=dmask)
+    ops.attn_fwd(desc)
+    ops.attn_bwd(desc)
+    keep = _decode_dropmask(dmask, B, heads, Lq, Lk)
+    rate = keep.float().mean().item()
+    assert abs(rate - (1 - p)) < 5 * math.sqrt(p * (1 - p) / keep.numel()) + 1e-4, f"keep rate {rate}"
+    m = kp.bool()[:, None, :].expand(B, Lq, Lk)
+    if flags & 1:
+        m = m | torch.eye(Lq, dtype=torch.bool, device="cuda")[None]
+    qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    Q = qr.view(B, Lq, heads, dh).transpose(1, 2)
+    K_, V_ = [t.view(B, Lk, heads, dh).transpose(1, 2) for t in kvr.split(H, dim=1)]
+    s = (Q @ K_.transpose(-1, -2)) * dh ** -0.5
+    s = s.masked_fill(~m[:, None], float("-inf"))
+    P = torch.softmax(s, -1)
+    oref = ((P * keep.float() / (1 - p)) @ V_).transpose(1, 2).reshape(B * Lq, H)
+    close_bf16(o, oref, "fast attn fwd with mask dropout", tol=2e-2)
+    close(lse, torch.logsumexp(s, -1), rtol=1e-3, atol=2e-3, msg="fast attn lse")
+    oref.backward(d_o.float())
+    close_bf16(dq, qr.grad, "fast attn dq", tol=3e-2)
+    close_bf16(dkv[:, :H], kvr.grad[:, :H], "fast attn dk", tol=3e-2)
+    close_bf16(dkv[:, H:], kvr.grad[:, H:], "fast attn dv", tol=3e-2)
+
+
+def test_attention_dropmask_statistics(ops):
+    """Keep bits of the mask generator at the bench head shape: rate, and no correlation between neighbouring queries / keys, the two
+    decisions of one hash (queries j and j + 16), heads, sites and steps (|corr| < 0.01; noise ~1e-3 on 1.3 M bits per head pair)."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    B, heads, L, dh, p = 4, 8, 200, 32, 0.4
+    H = heads * dh
+    qkv = torch.zeros(B * L, 3 * H, device="cuda", dtype=torch.bfloat16)
+    kp = torch.ones(B, L, dtype=torch.uint8, device="cuda")
+    o, lse = torch.empty(B * L, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, L, device="cuda")
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 77)
+
+    def mask(site):
+        dm = torch.zeros(ops.attn_dropmask_bytes(B, heads, L, L) // 4, dtype=torch.int32, device="cuda")
+        base = qkv.data_ptr()
+        desc = ops.attn_desc(Lb.BF16, B, heads, L, L, dh, base, base + H * 2, base + 2 * H * 2, 3 * H, 3 * H, 3 * H, o.data_ptr(), H, lse, kp, None, 0,
+                             dh ** -0.5, drop_p=ops.dropout(state, site, p), drop_mask=dm)
+        ops.attn_fwd(desc)
+        return _decode_dropmask(dm, B, heads, L, L).float()
+
+    k = mask(3)
+    var = p * (1 - p)
+    assert abs(k.mean().item() - (1 - p)) < 4 * math.sqrt(var / k.numel())
+    c = k - (1 - p)
+    corr = lambda a, b: (a * b).mean().item() / var
+    for lag in (1, 2, 16, 32):
+        assert abs(corr(c[:, :, :-lag], c[:, :, lag:])) < 0.01, f"query lag {lag}"
+        assert abs(corr(c[:, :, :, :-lag], c[:, :, :, lag:])) < 0.01, f"key lag {lag}"
+    assert abs(corr(c[:, :-1], c[:, 1:])) < 0.01 and abs(corr(c[:-1], c[1:])) < 0.01      # heads, samples
+    assert abs(corr(c, mask(4) - (1 - p))) < 0.01                                          # another site
+    assert torch.equal(k, mask(3))
+    ops.rng_advance(state)
+    assert abs(corr(c, mask(3) - (1 - p))) < 0.01                                          # next step
+
+
 @pytest.mark.parametrize("M,N,K,kc", [(204800 + 37, 768, 256, 1), (204800 + 37, 256, 768, 0), (204800, 512, 256, 1)])
 def test_gemm_bf16_full_size_many_tiles_per_workgroup(ops, M, N, K, kc):
     """BASELINE configs[1] row count (B = 1024 x 200 tokens): 4,800-9,600 output tiles, so the persistent bf16-output kernel walks
@@ -712,6 +812,30 @@ def test_dropout_pair_hash_statistics(ops):
     assert torch.equal(k, mask(3))                                       # same state, same site: same mask
     ops.rng_advance(state)
     assert abs(corr(c, mask(3) - (1 - p))) < 0.01                        # next step
+
+
+def test_dropout_hash_large_tensor_has_no_repeated_masks(ops):
+    """the 24-bit multiply of the pair hash dropped input bits 24..31, so element idx and idx ^ (1 << 25 | 1 << 9)
+    shared a decision and a [204800, 256] tensor repeated its mask at row lag 131072 (rows r and (r - 131072) ^ 2).  On a 2^26-element
+    tensor: no correlation at row lags 131070..131074 and no exact equality between the two halves related by that XOR."""
+    M, N, p = 262144, 256, 0.4                      # 2^26 elements
+    x = torch.ones(M, N, device="cuda", dtype=torch.bfloat16)
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 99)
+    y = torch.empty_like(x)
+    ops.dropout_apply(x, y, M, N, ops.dropout(state, 5, p))
+    k = (y != 0)
+    del x, y
+    assert abs(k.float().mean().item() - (1 - p)) < 4 * math.sqrt(p * (1 - p) / (M * N))
+    var = p * (1 - p)
+    c = k.float() - (1 - p)
+    for lag in (131070, 131071, 131072, 131073, 131074):
+        assert abs((c[:-lag] * c[lag:]).mean().item() / var) < 0.01, f"row lag {lag}"
+    # idx ^ (1 << 25 | 1 << 9): row ^ 131072, column pair ^ 2 (row index bit 17, element bit 9 = row bit 1 at N = 256)
+    flat = k.view(-1)
+    idx = torch.arange(0, 1 << 22, device="cuda", dtype=torch.int64) * 16 + 3
+    agree = (flat[idx] == flat[idx ^ ((1 << 25) | (1 << 9))]).float().mean().item()
+    assert abs(agree - (p * p + (1 - p) * (1 - p))) < 0.01, agree           # independent masks agree 52 % of the time, copies 100 %
 
 
 def test_gemm_bf16_gelu_polynomial_accuracy(ops):

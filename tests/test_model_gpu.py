@@ -57,6 +57,48 @@ def test_tiny_forward_backward_vs_reference_fixture(variant, objective):
         np.testing.assert_allclose(g, ref, rtol=2e-3, atol=3e-6 + 1e-4 * np.abs(ref).max(), err_msg=k)
 
 
+_MM_CASES = list(range(10))
+
+
+@pytest.mark.parametrize("cid", _MM_CASES)
+def test_masker_modes_through_engine_vs_reference_fixture(cid):
+    """SURVEY.md §8 row f4 on the DEVICE path: every masker mode (models/masker.py:95-167) set on `model.masker` after construction
+    (utils/eval_utils.py:63-67), eval_mask = None, through MultiModal.forward -> HIP engine -> backward, against
+    oracle/make_goldens.py:fx_masker_modes_model (the reference's own forward/backward).  Masks and n exact, loss / predictions /
+    gradient norms at fp32-parity tolerances, the generator and `random` streams consumed alike; a mode upstream cannot run on a
+    two-modality batch must raise the same exception type here."""
+    z, meta = load_npz("masker_modes_model.npz")
+    c = meta["cases"][cid]
+    model = build_model(tiny_config(max_F=meta["T"]), meta["n_ap"], meta["n_beh"], seed=0)
+    model.load_state_dict({k[3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd/")})
+    for k, v in c["set"].items():
+        setattr(model.masker, k, v)
+    model.cuda().train()
+    batch = {k.split("/")[-1]: torch.from_numpy(z[k]) for k in z.files if k.startswith("batch/")}
+    torch.manual_seed(31 + cid)
+    random.seed(41 + cid)
+    md = O.make_mod_dict(batch, "token_masking")
+    md["ap"]["inputs_regions"] = np.asarray([meta["regions"]] * meta["B"])
+    md = to_dev(md)
+    if c["raises"]:
+        with pytest.raises(Exception) as ei:
+            model(md)
+        assert type(ei.value).__name__ == c["raises"], f"upstream raises {c['raises']}, this path {type(ei.value).__name__}"
+        return
+    out = model(md)
+    out.loss.backward()
+    assert out.loss.item() == pytest.approx(c["loss"], rel=2e-5)
+    for m in ("ap", "behavior"):
+        assert int(out.mod_n_examples[m]) == c["n"][m]
+        np.testing.assert_array_equal(md[m]["inputs_mask"].cpu().numpy(), z[f"c{cid}/mask/{m}"])
+        assert out.mod_loss[m].item() == pytest.approx(c["mod_loss"][m], rel=5e-5, abs=1e-6)
+        np.testing.assert_allclose(out.mod_preds[m].cpu().numpy(), z[f"c{cid}/preds/{m}"], rtol=1e-4, atol=2e-5)
+    for k, prm in model.named_parameters():
+        gn = 0.0 if prm.grad is None else float(prm.grad.double().norm())
+        assert gn == pytest.approx(c["grad_norm"][k], rel=5e-3, abs=1e-8), k
+    assert float(torch.rand(1)) == c["after_rand"] and random.random() == c["after_random"]        # same draws consumed
+
+
 def test_default_config_scalars_vs_reference_fixture():
     g = load_json("default_scalars.json")
     model = build_model(load_config().model, 668, 2, seed=42).cuda().eval()
@@ -244,8 +286,10 @@ def test_trainer_epoch_vs_reference_fixture():
             b["neuron_regions"] = [["XX"] * B for _ in range(n_ap)]
             out.append(b)
         return out
+    cfg = load_config()
+    cfg["training"]["exact_masker_stream"] = True       # the fixture holds the reference's generator stream (trainer default: token masks only)
     tr = make_multimodal_trainer(model=model, train_dataloader=loader(0), eval_dataloader=loader(50), optimizer=opt, log_dir="/tmp",
-                                 accelerator=acc, lr_scheduler=sch, avail_mod=["ap", "behavior"], config=load_config(),
+                                 accelerator=acc, lr_scheduler=sch, avail_mod=["ap", "behavior"], config=cfg,
                                  modal_filter=dict(input=["ap", "behavior"], output=["ap", "behavior"]), mixed_training=True,
                                  num_neurons=[n_ap])
     random.seed(42)
