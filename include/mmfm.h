@@ -148,13 +148,7 @@ typedef struct {
     const void* d_o; int lddo;   /* grad wrt the out_proj input (i.e. AFTER drop_o) */
     void* dq; void* dk; void* dv;
     int lddq, lddk, lddv;
-    /* Optional keep-bit mask of drop_p, one bit per (b, head, query, key): mmfm_attn_dropmask_bytes(B, heads, Lq, Lk) bytes,
-     * 16-byte aligned, caller-owned.  With it the bf16 dh = 32 kernels of heads up to 224 keys take the probability dropout
-     * from the mask (mmfm_attn_fwd FILLS it from drop_p's counter state, mmfm_attn_bwd of the same call READS it back) instead
-     * of hashing per element; NULL (or any other shape / dtype): the kernels regenerate the mask from the counter hash. */
-    void* drop_mask; int64_t drop_mask_bytes;
 } mmfm_attn_desc;
-int64_t mmfm_attn_dropmask_bytes(int B, int heads, int Lq, int Lk);
 int mmfm_attn_fwd(const mmfm_attn_desc* d, mmfm_stream stream);
 int mmfm_attn_bwd(const mmfm_attn_desc* d, mmfm_stream stream);
 

@@ -49,8 +49,7 @@ class AttnDesc(C.Structure):
                 ("ldv", C.c_int), ("o", C.c_void_p), ("ldo", C.c_int), ("lse", C.c_void_p), ("keypad", C.c_void_p),
                 ("mod_id", C.c_void_p), ("flags", C.c_int), ("scale", C.c_float), ("drop_p", Dropout),
                 ("drop_o", Dropout), ("d_o", C.c_void_p), ("lddo", C.c_int), ("dq", C.c_void_p), ("dk", C.c_void_p),
-                ("dv", C.c_void_p), ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int),
-                ("drop_mask", C.c_void_p), ("drop_mask_bytes", C.c_int64)]
+                ("dv", C.c_void_p), ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int)]
 
 
 class PrepEntry(C.Structure):
@@ -93,7 +92,6 @@ _PROTOS = {
     "mmfm_layernorm_fwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _f, _i, _i, _vp]),
     "mmfm_layernorm_bwd_workspace": (C.c_int64, [_i64, _i]),
     "mmfm_layernorm_bwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _i64, _vp]),
-    "mmfm_attn_dropmask_bytes": (C.c_int64, [C.c_int, C.c_int, C.c_int, C.c_int]),
     "mmfm_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "mmfm_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "mmfm_mask_prep": (C.c_int, [_i, _i, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _vp]),

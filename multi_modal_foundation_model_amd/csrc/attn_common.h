@@ -83,4 +83,36 @@ __device__ __forceinline__ void store_tile_T(char* tile, int RS, const f32x16 (&
     }
 }
 
+// ---- attention-probability dropout, shared by the general and the fast kernels
+// Dropout on the probabilities.  One hash decides a PAIR of keys (even key: low 16 bits, odd key: high 16 bits, each against
+// the top 16 bits of the threshold).  The hash is two-level: a full-strength 2 x 32-bit ROW key per (batch, head, query)
+// - computed once per query tile (forward, dQ phase: lane = query) or once per workgroup into an LDS table (dK/dV phase:
+// lane = key) - and a 7-instruction xorshift / 24-bit-multiply mix of (pair index ^ key A, key B) per pair.  Forward and
+// both backward phases evaluate the same function, so no mask is stored.  v_mul_u32_u24 issues at the full VALU rate,
+// v_mul_lo_u32 at a quarter of it, and a step draws ~10^9 of these decisions: the round-1 version (11 instructions per pair
+// on a linear pair index, plus a 32-bit multiply to form that index in the dK/dV phase) was ~40 % of the forward tile's VALU work.
+struct Drop16 {
+    uint32_t k0, k1, t16;
+    float scale;
+    bool on;
+    __device__ __forceinline__ void rowkeys(uint32_t rowid, uint32_t& ka, uint32_t& kb) const {       // rowid = bh * Lq + q
+        ka = mix32(rowid ^ k0);
+        kb = mix32((rowid + 0x9E3779B9u) ^ k1);
+    }
+    // jx = (key >> 1) ^ ka
+    __device__ __forceinline__ uint32_t hash(uint32_t jx, uint32_t kb) const {
+        uint32_t h = __umul24(jx, 0x7FEB35u) + kb;
+        h ^= h >> 13;
+        h = __umul24(h, 0x46CA6Bu);
+        h ^= h >> 16;
+        return h;
+    }
+};
+__device__ __forceinline__ Drop16 drop16_init(mmfm_dropout d) {
+    const Drop b = drop_init(d);
+    Drop16 r;
+    r.k0 = b.k0; r.k1 = b.k1; r.t16 = b.thresh >> 16; r.scale = b.scale; r.on = b.on();
+    return r;
+}
+
 }  // namespace attn

@@ -59,7 +59,9 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(int kind, const T* __rest
         const bool on = rowmask[(row / Tn) * mask_ld + (row % Tn)] != 0;
         for (int c = lane; c < N; c += 64) {
             const size_t o = (size_t)row * N + c;
-            io<T>::st(dpred + o, on ? g * loss_grad(kind, io<T>::ld(pred + o), target[o]) : 0.f);
+            // unmasked rows: mask * g with mask = 0 - i.e. 0 normally, NaN when nothing at all is masked (g = grad / 0 = inf), which is
+            // what upstream's (loss * mask).sum() / mask.sum() hands to autograd (mm.py:217-239): every gradient of that step is NaN there
+            io<T>::st(dpred + o, on ? g * loss_grad(kind, io<T>::ld(pred + o), target[o]) : g * 0.f);
         }
     }
 }

@@ -96,7 +96,7 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, R, H, ws, a
 
 
 def attn_desc(dtype, B, heads, Lq, Lk, dh, q, k, v, ldq, ldk, ldv, o, ldo, lse, keypad, mod_id, flags, scale,
-              drop_p=None, drop_o=None, d_o=None, lddo=0, dq=None, dk=None, dv=None, lddq=0, lddk=0, lddv=0, drop_mask=None):
+              drop_p=None, drop_o=None, d_o=None, lddo=0, dq=None, dk=None, dv=None, lddq=0, lddk=0, lddv=0):
     d = L.AttnDesc()
     d.dtype, d.B, d.heads, d.Lq, d.Lk, d.dh = dtype, B, heads, Lq, Lk, dh
     d.q, d.k, d.v, d.ldq, d.ldk, d.ldv = q, k, v, ldq, ldk, ldv
@@ -104,13 +104,7 @@ def attn_desc(dtype, B, heads, Lq, Lk, dh, q, k, v, ldq, ldk, ldv, o, ldo, lse, 
     d.drop_p = drop_p if drop_p is not None else L.NO_DROP
     d.drop_o = drop_o if drop_o is not None else L.NO_DROP
     d.d_o, d.lddo, d.dq, d.dk, d.dv, d.lddq, d.lddk, d.lddv = d_o, lddo, dq, dk, dv, lddq, lddk, lddv
-    d.drop_mask = P(drop_mask)
-    d.drop_mask_bytes = drop_mask.numel() * drop_mask.element_size() if drop_mask is not None else 0
     return d
-
-
-def attn_dropmask_bytes(B, heads, Lq, Lk):
-    return int(L.lib().mmfm_attn_dropmask_bytes(B, heads, Lq, Lk))
 
 
 def attn_fwd(desc, plan=None):

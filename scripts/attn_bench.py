@@ -22,11 +22,9 @@ dqkv = torch.empty(B * L, 3 * H, device="cuda", dtype=td)
 state = torch.zeros(2, dtype=torch.int32, device="cuda")
 ops.rng_seed(state, 7)
 base = qkv.data_ptr()
-use_mask = os.environ.get("MMFM_ATTN_MASK", "1") != "0" and dtype == "bf16" and p > 0
-dmask = torch.zeros(ops.attn_dropmask_bytes(B, heads, L, L) // 4, dtype=torch.int32, device="cuda") if use_mask else None
 desc = ops.attn_desc(Lb.BF16 if dtype == "bf16" else Lb.F32, B, heads, L, L, dh, base, base + H * es, base + 2 * H * es, 3 * H, 3 * H, 3 * H, o.data_ptr(), H, lse, kp,
                      None, 1, 1 / math.sqrt(dh), drop_p=ops.dropout(state, 3, p), drop_o=ops.dropout(state, 4, p), d_o=d_o.data_ptr(), lddo=H,
-                     dq=dqkv.data_ptr(), dk=dqkv.data_ptr() + H * es, dv=dqkv.data_ptr() + 2 * H * es, lddq=3 * H, lddk=3 * H, lddv=3 * H, drop_mask=dmask)
+                     dq=dqkv.data_ptr(), dk=dqkv.data_ptr() + H * es, dv=dqkv.data_ptr() + 2 * H * es, lddq=3 * H, lddk=3 * H, lddv=3 * H)
 for fn, name, fl in ((ops.attn_fwd, "fwd", 4.0), (ops.attn_bwd, "bwd", 10.0)):
     fn(desc); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -35,4 +33,4 @@ for fn, name, fl in ((ops.attn_fwd, "fwd", 4.0), (ops.attn_bwd, "bwd", 10.0)):
         fn(desc)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print(f"attn_{name} {dtype} B={B} p={p} mask={int(use_mask)}: {ms*1e3:.1f} us  {fl*B*heads*L*L*dh/ms/1e9:.1f} TFLOP/s")
+    print(f"attn_{name} {dtype} B={B} p={p}: {ms*1e3:.1f} us  {fl*B*heads*L*L*dh/ms/1e9:.1f} TFLOP/s")

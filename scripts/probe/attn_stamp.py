@@ -15,12 +15,11 @@ state = torch.zeros(2, dtype=torch.int32, device="cuda"); ops.rng_seed(state, 7)
 lib = Lb.lib()
 lib.mmfm_attn_probe_read.argtypes = [C.POINTER(C.c_ulonglong), C.c_int]
 buf = (C.c_ulonglong * 16)()
-names = ["prologue: K/V/bias -> LDS", "barrier + vote", "Q load, first score, first masks", "key-tile loop", "epilogue (normalise, stage, store)"]
+names = ["prologue: K/V/bias -> LDS", "barrier + vote", "Q operands, first score tile", "key-tile loop", "epilogue (normalise, stage, store)"]
 for p in (0.0, 0.4):
-    dm = torch.zeros(ops.attn_dropmask_bytes(B, heads, L, L) // 4, dtype=torch.int32, device="cuda") if p else None
     base = qkv.data_ptr()
     desc = ops.attn_desc(Lb.BF16, B, heads, L, L, dh, base, base + H * 2, base + 2 * H * 2, 3 * H, 3 * H, 3 * H, o.data_ptr(), H, lse, kp, None, 1,
-                         1 / math.sqrt(dh), drop_p=ops.dropout(state, 3, p) if p else None, drop_o=ops.dropout(state, 4, p) if p else None, drop_mask=dm)
+                         1 / math.sqrt(dh), drop_p=ops.dropout(state, 3, p) if p else None, drop_o=ops.dropout(state, 4, p) if p else None)
     ops.attn_fwd(desc); torch.cuda.synchronize(); lib.mmfm_attn_probe_read(buf, 1)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); ops.attn_fwd(desc); e1.record(); torch.cuda.synchronize()

@@ -617,27 +617,37 @@ def test_attention_bf16_dropout_consistency(ops, L, dh):
     close(dv.sum(1), o.float().view(B, L, heads, dh)[..., 0].sum(1), rtol=2e-2, atol=0.5, msg="bf16 fwd/bwd dropout mask agree")
 
 
-def _decode_dropmask(buf, B, heads, Lq, Lk):
-    """keep[b, h, q, k] out of the mmfm_attn_desc.drop_mask layout [b*heads][query tile][key tile][32 words]: word w of a tile is key
-    mrow(w >> 1, w & 1) = ((w>>1)&3) + 8*((w>>1)>>2) + 4*(w&1), bit i is query i of the tile (include/mmfm.h, csrc/attention_fast.hip)."""
-    nqt, nkt = (Lq + 31) // 32, (Lk + 31) // 32
-    wds = buf.view(B * heads, nqt, nkt, 32).to(torch.int64) & 0xFFFFFFFF
-    w = torch.arange(32, device=buf.device)
-    key_of_w = ((w >> 1) & 3) + 8 * ((w >> 1) >> 2) + 4 * (w & 1)
-    bits = (wds[..., None] >> torch.arange(32, device=buf.device)) & 1                 # [bh, qt, kt, w, i]
-    keep = torch.zeros(B * heads, nqt, nkt, 32, 32, dtype=torch.bool, device=buf.device)  # [bh, qt, kt, key_local, i]
-    keep[:, :, :, key_of_w, :] = bits.bool()
-    keep = keep.permute(0, 1, 4, 2, 3).reshape(B * heads, nqt * 32, nkt * 32)           # [bh, q, k]
-    return keep[:, :Lq, :Lk].reshape(B, heads, Lq, Lk)
+def _extract_attn_keep_mask(ops, state, site, p, B, heads, Lq, Lk):
+    """keep[b, h, q, k] of the attention-probability dropout at (state, site), read off the kernel itself: the decisions depend on
+    (state, site, b, head, query, key) only, not on the data, so with q = k = 0 (uniform probabilities 1 / Lk) and a one-hot V block
+    (V[k, d] = 1 iff k == 32 blk + d) the forward output is keep(q, 32 blk + d) / (Lk (1 - p)): ceil(Lk / 32) launches show every key."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    dh = 32
+    H = heads * dh
+    q = torch.zeros(B * Lq, H, device="cuda", dtype=torch.bfloat16)
+    kp = torch.ones(B, Lk, dtype=torch.uint8, device="cuda")
+    keep = torch.zeros(B, heads, Lq, Lk, dtype=torch.bool, device="cuda")
+    for blk in range((Lk + 31) // 32):
+        kv = torch.zeros(B, Lk, 2, heads, dh, device="cuda", dtype=torch.bfloat16)
+        n = min(32, Lk - 32 * blk)
+        kv[:, 32 * blk + torch.arange(n), 1, :, torch.arange(n)] = 1.0
+        kv = kv.view(B * Lk, 2 * H)
+        o, lse = torch.empty(B * Lq, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, Lq, device="cuda")
+        desc = ops.attn_desc(Lb.BF16, B, heads, Lq, Lk, dh, q.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * 2, H, 2 * H, 2 * H, o.data_ptr(), H, lse,
+                             kp, None, 0, dh ** -0.5, drop_p=ops.dropout(state, site, p))
+        ops.attn_fwd(desc)
+        keep[:, :, :, 32 * blk:32 * blk + n] = (o.view(B, Lq, heads, dh).permute(0, 2, 1, 3)[..., :n] != 0)
+    return keep
 
 
 @pytest.mark.parametrize("B,heads,Lq,Lk,flags,pad", [(2, 8, 200, 200, 1, True), (2, 8, 200, 200, 0, False), (3, 4, 72, 40, 0, True), (2, 4, 224, 224, 1, False),
                                                      (2, 2, 104, 104, 1, True)])
-def test_attention_fast_dropmask_matches_reference(ops, B, heads, Lq, Lk, flags, pad):
-    """The dh = 32 fast pair (csrc/attention_fast.hip) with attention-probability dropout drawn from the precomputed keep mask: the
-    forward fills drop_mask, the test decodes it and evaluates softmax -> mask / (1 - p) -> P.V in torch fp32 on the same bf16 inputs;
-    output, LSE and all three gradients must match.  Keys 150.. carry 6x larger rows so that the running maximum jumps late in the
-    key sweep by more than the lazy-rescale threshold (cdna_hip_programming.md rule 26: force the rare branch)."""
+def test_attention_fast_dropout_matches_reference(ops, B, heads, Lq, Lk, flags, pad):
+    """The dh = 32 fast pair (csrc/attention_fast.hip) WITH attention-probability dropout against torch fp32 on the same bf16 inputs:
+    the keep mask is read off the kernel (see _extract_attn_keep_mask), then softmax -> mask / (1 - p) -> P.V and its autograd give
+    the expected output, LSE and all three gradients (forward and backward must regenerate the SAME decisions).  Keys of the last
+    quarter carry 6x larger rows so that the running maximum jumps late in the key sweep by more than the lazy-rescale threshold
+    (cdna_hip_programming.md rule 26: force the rare branch)."""
     from multi_modal_foundation_model_amd import _lib as Lb
     dh, p = 32, 0.4
     H = heads * dh
@@ -653,17 +663,16 @@ def test_attention_fast_dropmask_matches_reference(ops, B, heads, Lq, Lk, flags,
     kp = kp.cuda()
     state = torch.zeros(2, dtype=torch.int32, device="cuda")
     ops.rng_seed(state, 4321)
-    dmask = torch.zeros(ops.attn_dropmask_bytes(B, heads, Lq, Lk) // 4, dtype=torch.int32, device="cuda")
+    keep = _extract_attn_keep_mask(ops, state, 7, p, B, heads, Lq, Lk)
+    rate = keep.float().mean().item()
+    assert abs(rate - (1 - p)) < 5 * math.sqrt(p * (1 - p) / keep.numel()) + 1e-4, f"keep rate {rate}"
     o, lse = torch.empty(B * Lq, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, Lq, device="cuda")
     dq, dkv = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
     desc = ops.attn_desc(Lb.BF16, B, heads, Lq, Lk, dh, q.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * 2, H, 2 * H, 2 * H, o.data_ptr(), H, lse,
                          kp, None, flags, dh ** -0.5, drop_p=ops.dropout(state, 7, p), d_o=d_o.data_ptr(), lddo=H, dq=dq.data_ptr(),
-                         dk=dkv.data_ptr(), dv=dkv.data_ptr() + H * 2, lddq=H, lddk=2 * H, lddv=2 * H, drop_mask=dmask)
+                         dk=dkv.data_ptr(), dv=dkv.data_ptr() + H * 2, lddq=H, lddk=2 * H, lddv=2 * H)
     ops.attn_fwd(desc)
     ops.attn_bwd(desc)
-    keep = _decode_dropmask(dmask, B, heads, Lq, Lk)
-    rate = keep.float().mean().item()
-    assert abs(rate - (1 - p)) < 5 * math.sqrt(p * (1 - p) / keep.numel()) + 1e-4, f"keep rate {rate}"
     m = kp.bool()[:, None, :].expand(B, Lq, Lk)
     if flags & 1:
         m = m | torch.eye(Lq, dtype=torch.bool, device="cuda")[None]
@@ -674,7 +683,7 @@ def test_attention_fast_dropmask_matches_reference(ops, B, heads, Lq, Lk, flags,
     s = s.masked_fill(~m[:, None], float("-inf"))
     P = torch.softmax(s, -1)
     oref = ((P * keep.float() / (1 - p)) @ V_).transpose(1, 2).reshape(B * Lq, H)
-    close_bf16(o, oref, "fast attn fwd with mask dropout", tol=2e-2)
+    close_bf16(o, oref, "fast attn fwd with dropout", tol=2e-2)
     close(lse, torch.logsumexp(s, -1), rtol=1e-3, atol=2e-3, msg="fast attn lse")
     oref.backward(d_o.float())
     close_bf16(dq, qr.grad, "fast attn dq", tol=3e-2)
@@ -682,39 +691,26 @@ def test_attention_fast_dropmask_matches_reference(ops, B, heads, Lq, Lk, flags,
     close_bf16(dkv[:, H:], kvr.grad[:, H:], "fast attn dv", tol=3e-2)
 
 
-def test_attention_dropmask_statistics(ops):
-    """Keep bits of the mask generator at the bench head shape: rate, and no correlation between neighbouring queries / keys, the two
-    decisions of one hash (queries j and j + 16), heads, sites and steps (|corr| < 0.01; noise ~1e-3 on 1.3 M bits per head pair)."""
-    from multi_modal_foundation_model_amd import _lib as Lb
-    B, heads, L, dh, p = 4, 8, 200, 32, 0.4
-    H = heads * dh
-    qkv = torch.zeros(B * L, 3 * H, device="cuda", dtype=torch.bfloat16)
-    kp = torch.ones(B, L, dtype=torch.uint8, device="cuda")
-    o, lse = torch.empty(B * L, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, L, device="cuda")
+def test_attention_fast_dropout_statistics(ops):
+    """Keep decisions of the fast attention pair at the bench head shape: rate, and no correlation between neighbouring queries / keys,
+    the two decisions of one hash (keys 2j, 2j + 1), heads, samples, sites and steps (|corr| < 0.01; noise ~1e-3 on 1.3 M bits)."""
+    B, heads, L, p = 4, 8, 200, 0.4
     state = torch.zeros(2, dtype=torch.int32, device="cuda")
     ops.rng_seed(state, 77)
-
-    def mask(site):
-        dm = torch.zeros(ops.attn_dropmask_bytes(B, heads, L, L) // 4, dtype=torch.int32, device="cuda")
-        base = qkv.data_ptr()
-        desc = ops.attn_desc(Lb.BF16, B, heads, L, L, dh, base, base + H * 2, base + 2 * H * 2, 3 * H, 3 * H, 3 * H, o.data_ptr(), H, lse, kp, None, 0,
-                             dh ** -0.5, drop_p=ops.dropout(state, site, p), drop_mask=dm)
-        ops.attn_fwd(desc)
-        return _decode_dropmask(dm, B, heads, L, L).float()
-
-    k = mask(3)
+    k = _extract_attn_keep_mask(ops, state, 3, p, B, heads, L, L).float()
     var = p * (1 - p)
     assert abs(k.mean().item() - (1 - p)) < 4 * math.sqrt(var / k.numel())
     c = k - (1 - p)
     corr = lambda a, b: (a * b).mean().item() / var
+    assert abs(corr(c[..., 0::2], c[..., 1::2])) < 0.01                                   # the two keys of one hash
     for lag in (1, 2, 16, 32):
         assert abs(corr(c[:, :, :-lag], c[:, :, lag:])) < 0.01, f"query lag {lag}"
         assert abs(corr(c[:, :, :, :-lag], c[:, :, :, lag:])) < 0.01, f"key lag {lag}"
     assert abs(corr(c[:, :-1], c[:, 1:])) < 0.01 and abs(corr(c[:-1], c[1:])) < 0.01      # heads, samples
-    assert abs(corr(c, mask(4) - (1 - p))) < 0.01                                          # another site
-    assert torch.equal(k, mask(3))
+    assert abs(corr(c, _extract_attn_keep_mask(ops, state, 4, p, B, heads, L, L).float() - (1 - p))) < 0.01          # another site
+    assert torch.equal(k, _extract_attn_keep_mask(ops, state, 3, p, B, heads, L, L).float())
     ops.rng_advance(state)
-    assert abs(corr(c, mask(3) - (1 - p))) < 0.01                                          # next step
+    assert abs(corr(c, _extract_attn_keep_mask(ops, state, 3, p, B, heads, L, L).float() - (1 - p))) < 0.01          # next step
 
 
 @pytest.mark.parametrize("M,N,K,kc", [(204800 + 37, 768, 256, 1), (204800 + 37, 256, 768, 0), (204800, 512, 256, 1)])

@@ -87,15 +87,15 @@ def test_masker_modes_through_engine_vs_reference_fixture(cid):
         return
     out = model(md)
     out.loss.backward()
-    assert out.loss.item() == pytest.approx(c["loss"], rel=2e-5)
+    assert out.loss.item() == pytest.approx(c["loss"], rel=2e-5, nan_ok=True)      # nothing masked (channel 0 of co-smooth): 0/0 = NaN upstream too
     for m in ("ap", "behavior"):
         assert int(out.mod_n_examples[m]) == c["n"][m]
         np.testing.assert_array_equal(md[m]["inputs_mask"].cpu().numpy(), z[f"c{cid}/mask/{m}"])
-        assert out.mod_loss[m].item() == pytest.approx(c["mod_loss"][m], rel=5e-5, abs=1e-6)
+        assert out.mod_loss[m].item() == pytest.approx(c["mod_loss"][m], rel=5e-5, abs=1e-6, nan_ok=True)
         np.testing.assert_allclose(out.mod_preds[m].cpu().numpy(), z[f"c{cid}/preds/{m}"], rtol=1e-4, atol=2e-5)
     for k, prm in model.named_parameters():
         gn = 0.0 if prm.grad is None else float(prm.grad.double().norm())
-        assert gn == pytest.approx(c["grad_norm"][k], rel=5e-3, abs=1e-8), k
+        assert gn == pytest.approx(c["grad_norm"][k], rel=5e-3, abs=1e-8, nan_ok=True), k
     assert float(torch.rand(1)) == c["after_rand"] and random.random() == c["after_random"]        # same draws consumed
 
 
