@@ -308,6 +308,28 @@ class Engine:
                                  # (measured, un-fused vs fused ms/step: B=16 4.80 / 5.00, B=32 5.24 / 5.32, B=64 6.31 / 6.21, B=128 8.55 / 7.66)
         return int(os.environ.get("MMFM_FUSED", "15")) & 15        # default: everything fused, the fastest end to end (35.6 vs 36.3 ms)
 
+    # ------------------------------------------------------------------ bf16 transposes for the compute-bound dX products
+    def _w_transposed(self, wname, N, Kd, Mr):
+        """W^T [Kd, N] (bf16) of an nn.Linear weight [N, Kd] when its dX = dY[Mr, N] . W belongs to the 256-tile GEMM (csrc/gemm_big.hip:
+        reduction N a multiple of 64 and >= 512; d_model-512 configurations and any layer this wide): that kernel wants both operands
+        reduction-contiguous.  The views are refreshed by ONE mmfm_prep_weights launch at the top of every training step."""
+        if os.environ.get("MMFM_GEMM_BIG", "1") == "0" or N < 512 or N % 64 or Kd % 8 or Kd < 128 or Mr < 1024:
+            return None
+        reg = self.__dict__.setdefault("_wt", dict(views={}, entries=[], table=None))
+        if wname not in reg["views"]:
+            t = torch.zeros(Kd, N, dtype=torch.bfloat16, device=self.device)
+            reg["views"][wname] = t
+            reg["entries"].append(dict(W=self.Pf(wname + ".weight"), WpT=t))
+            reg["table"] = None
+        return reg["views"][wname]
+
+    def _wt_table(self):
+        reg = self._wt
+        if reg["table"] is None:
+            table, n, tiles = K.prep_table(reg["entries"], self.device)
+            reg["table"] = dict(table=table, n=n, tiles=tiles)
+        return reg["table"]
+
     def _build_prep(self):
         """Prepared weights of the fused path: per LayerNorm-fed linear Wp = bf16(W * gamma), WpT, bp = b + W beta
         (mmfm_prep_weights); per plain linear only the bf16 transpose (the dX products read K-contiguous rows)."""
@@ -423,6 +445,8 @@ class Engine:
             K.gemm(X, self.W(wname + ".weight"), Y, Mr, N, Kd, lda=Kd, ldb=Kd, ldc=N, bias=self.Pf(wname + ".bias"),
                    dtype=code, plan=plan, **kw)
 
+        used_wt: list = []
+
         def dlin(plan, dY, X, wname, Mr, N, Kd, dX=None, **kw):
             """Backward of Y[Mr,N] = X[Mr,Kd] @ W[N,Kd]^T + b:  dW, db into G;  dX = dY @ W (optional, fused epilogue)."""
             S, kchunk = self._dw_split(N, Kd, Mr)
@@ -454,7 +478,12 @@ class Engine:
             if not fused or (S > 1 and not adjacent):
                 K.colsum(dY, Mr, N, N, gb, ws_col, plan=plan)
             if dX is not None:
-                K.gemm(dY, self.W(wname + ".weight"), dX, Mr, Kd, N, lda=N, ldb=Kd, ldc=Kd, b_kcontig=0, dtype=code, plan=plan, **kw)
+                wT = self._w_transposed(wname, N, Kd, Mr) if fused else None
+                if wT is not None:      # reduction >= 512: the 256-tile kernel (csrc/gemm_big.hip) against the K-contiguous transpose W^T [Kd, N]
+                    used_wt.append(wname)
+                    K.gemm(dY, wT, dX, Mr, Kd, N, lda=N, ldb=N, ldc=Kd, b_kcontig=1, dtype=code, plan=plan, **kw)
+                else:
+                    K.gemm(dY, self.W(wname + ".weight"), dX, Mr, Kd, N, lda=N, ldb=Kd, ldc=Kd, b_kcontig=0, dtype=code, plan=plan, **kw)
 
         def ln_f(plan, X, name, Y, tag, **kw):
             K.layernorm_fwd(X, self.Pf(name + ".weight"), self.Pf(name + ".bias"), Y, buf(tag + "/mean", (R,), f32),
@@ -733,6 +762,10 @@ class Engine:
                      act=L.ACT_SOFTSIGN_GRAD, act_scale=c.embed_scale, gradmul_pre=self.b[f"{side}/z/{m}"])
                 dlin(cur, dz, self.b[f"in/{m}"], p + ".token_embed", BT, n2, n)
         close_segment("embed")
+        if used_wt:                 # refresh the bf16 transposes once per step, in front of everything (the optimiser rewrote the weights)
+            tw = self._wt_table()
+            K.prep_weights(tw["table"], tw["n"], tw["tiles"], plan=fwd)
+            fwd.insert(0, fwd.pop())
         plan = dict(fwd=fwd, bwd=bwd, B=B, T=T, training=bool(training), M=M, R=R, BT=BT, runs=dict(fwd=0, bwd=0), graphs={}, b=self.b)
         self.plans[key] = plan
         return plan

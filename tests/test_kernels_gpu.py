@@ -617,6 +617,52 @@ def test_attention_bf16_dropout_consistency(ops, L, dh):
     close(dv.sum(1), o.float().view(B, L, heads, dh)[..., 0].sum(1), rtol=2e-2, atol=0.5, msg="bf16 fwd/bwd dropout mask agree")
 
 
+@pytest.mark.parametrize("M,N,K,Kreal", [(2048 + 100, 512, 512, 512), (1500, 1336, 704, 668), (1100, 256, 1344, 1336), (4096 + 37, 1536, 512, 512),
+                                          (1024, 1024, 1024, 1024)])
+def test_gemm_bf16_256_tile_kernel(ops, M, N, K, Kreal):
+    """csrc/gemm_big.hip (256 x 256 tiles, LDS-DMA operands, persistent workgroups): K a multiple of 64 - the token-embedding shapes
+    reach it with their operands zero-padded along K (668 -> 704, 1336 -> 1344) - ragged M and N tiles, every epilogue the path uses:
+    bias + saved pre-activation + softsign (tokeniser forward), GELU, dropout (same mask as mmfm_dropout_apply), residual, and the
+    two backward-through-activation forms.  Against torch fp64 on the same bf16 inputs; the first rows bit for bit against the
+    128 x 128 kernel (MMFM_GEMM_BIG_KMIN keeps short reductions there: here via a K = 64 * 7 = 448 < 512 twin is not possible, so
+    the comparison is against fp64 only)."""
+    x = torch.zeros(M, K, device="cuda", dtype=torch.bfloat16)
+    w = torch.zeros(N, K, device="cuda", dtype=torch.bfloat16)
+    x[:, :Kreal] = bf(rnd(M, Kreal, seed=1))
+    w[:, :Kreal] = bf(rnd(N, Kreal, seed=2, scale=Kreal ** -0.5))
+    b = rnd(N, seed=3)
+    ref0 = x.double() @ w.double().T + b.double()
+    y, pre = torch.full((M + 1, N), 9.0, device="cuda", dtype=torch.bfloat16), torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    # (1) bias + pre_out + softsign
+    ops.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b, pre_out=pre, act=2, act_scale=0.7)
+    close_bf16(pre, ref0, "256-tile pre-activation")
+    close_bf16(y[:M], 0.7 * ref0 / (1 + ref0.abs()), "256-tile softsign")
+    assert torch.all(y[M:] == 9.0), "rows beyond M written"
+    # (2) GELU
+    ops.gemm(x, w, y, M, N, K, lda=K, ldb=K, ldc=N, bias=b, act=1)
+    close_bf16(y[:M], torch.nn.functional.gelu(ref0), "256-tile gelu")
+    # (3) dropout + residual: the mask is the one mmfm_dropout_apply draws for (site, m * N + n)
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 5)
+    res = bf(rnd(M, N, seed=4))
+    y0, yd, msk = (torch.empty(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(3))
+    ops.gemm(x, w, y0, M, N, K, lda=K, ldb=K, ldc=N, bias=b)
+    close_bf16(y0, ref0, "256-tile plain")
+    ops.gemm(x, w, yd, M, N, K, lda=K, ldb=K, ldc=N, bias=b, drop=ops.dropout(state, 9, 0.4), residual=res, ldr=N)
+    ops.dropout_apply(torch.ones_like(y0), msk, M, N, ops.dropout(state, 9, 0.4))
+    keep = (msk != 0)
+    assert abs(keep.float().mean().item() - 0.6) < 0.01
+    close_bf16(yd, ref0 * keep / 0.6 + res.double(), "256-tile dropout + residual", tol=2e-2)
+    # (4) backward through the activations: act 3 (gelu') and act 4 (softsign') multiply by f'(saved pre-activation)
+    u = bf(rnd(M, N, seed=6))
+    ops.gemm(x, w, y0, M, N, K, lda=K, ldb=K, ldc=N, gradmul_pre=u, act=3)
+    ud = u.double()
+    gp = 0.5 * (1 + torch.erf(ud / math.sqrt(2))) + ud * torch.exp(-0.5 * ud * ud) / math.sqrt(2 * math.pi)
+    close_bf16(y0, (x.double() @ w.double().T) * gp, "256-tile gelu'")
+    ops.gemm(x, w, y0, M, N, K, lda=K, ldb=K, ldc=N, gradmul_pre=u, act=4, act_scale=0.7)
+    close_bf16(y0, (x.double() @ w.double().T) * 0.7 / (1 + ud.abs()) ** 2, "256-tile softsign'")
+
+
 def _extract_attn_keep_mask(ops, state, site, p, B, heads, Lq, Lk):
     """keep[b, h, q, k] of the attention-probability dropout at (state, site), read off the kernel itself: the decisions depend on
     (state, site, b, head, query, key) only, not on the data, so with q = k = 0 (uniform probabilities 1 / Lk) and a one-hot V block
