@@ -57,6 +57,8 @@ int mmfm_rng_advance(void* state, mmfm_stream stream);
  *   act 1: v = gelu_erf(v)           act 2: v = softsign(v) * act_scale          (forward)
  *   act 3: v *= gelu_erf'(gradmul_pre[m*ldc+n])   act 4: v *= softsign'(gradmul_pre[..]) * act_scale
  *          (backward through the activation whose pre-activation the forward stored via pre_out);
+ *   act 5: v *= (1 - |y| / act_scale)^2 * act_scale with y = gradmul_pre[..] the forward's act-2 OUTPUT: the same softsign'
+ *          without a saved pre-activation (bf16 throughput mode; the fp32 parity path keeps act 4);
  *   v = dropout(v) (counter m*N+n);  v += residual[m*ldr+n];  C[m*ldc+n] = v
  */
 typedef struct {

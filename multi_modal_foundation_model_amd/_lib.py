@@ -20,7 +20,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "mmfm.h")
 
 F32, BF16 = 0, 1
 ATTN_DIAG, ATTN_CAUSAL, ATTN_SEP = 1, 2, 4
-ACT_NONE, ACT_GELU, ACT_SOFTSIGN, ACT_GELU_GRAD, ACT_SOFTSIGN_GRAD = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_SOFTSIGN, ACT_GELU_GRAD, ACT_SOFTSIGN_GRAD, ACT_SOFTSIGN_GRAD_OUT = 0, 1, 2, 3, 4, 5
 
 
 class MmfmError(RuntimeError):

@@ -219,6 +219,9 @@ template <int N> __device__ __forceinline__ void mul_gelu_grad_n(float* v, const
 }
 __device__ __forceinline__ float softsign_f(float x) { return x / (1.f + fabsf(x)); }
 __device__ __forceinline__ float softsign_grad(float x) { float d = 1.f + fabsf(x); return 1.f / (d * d); }
+// the same derivative from the activation's OUTPUT y = s * x / (1 + |x|):  1 / (1 + |x|) = 1 - |y| / s  (act 5: the tokeniser's
+// backward reads the activation it needs anyway instead of a second, saved [rows, 1336] pre-activation tensor)
+__device__ __forceinline__ float softsign_grad_from_out(float y, float inv_s) { const float r = 1.f - fabsf(y) * inv_s; return r * r; }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

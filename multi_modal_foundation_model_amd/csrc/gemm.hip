@@ -98,7 +98,7 @@ __device__ __forceinline__ void epilogue_store(const mmfm_gemm_desc& d, const Dr
     if (d.gradmul_pre) {
         const float u = O::ld(reinterpret_cast<const TO*>(d.gradmul_pre) + (size_t)m * d.ldc + n);
         // act kinds 3/4 = multiply by gelu'(u) / softsign'(u)*scale (backward through the activation)
-        v *= (d.act == 3) ? gelu_erf_grad(u) : softsign_grad(u) * d.act_scale;
+        v *= (d.act == 3) ? gelu_erf_grad(u) : (d.act == 4 ? softsign_grad(u) : softsign_grad_from_out(u, 1.f / d.act_scale)) * d.act_scale;
     }
     v = dr.apply(v, (uint64_t)m * (uint64_t)d.N + (uint64_t)n);
     if (d.residual) v += O::ld(reinterpret_cast<const TO*>(d.residual) + (size_t)m * d.ldr + n);
@@ -305,8 +305,8 @@ extern "C" int mmfm_gemm(const mmfm_gemm_desc* dp, mmfm_stream stream) {
     MMFM_REQUIRE(d.ldb >= (d.b_kcontig ? d.K : d.N), "mmfm_gemm: ldb %d too small", d.ldb);
     MMFM_REQUIRE(d.ldc >= d.N, "mmfm_gemm: ldc %d < N %d", d.ldc, d.N);
     MMFM_REQUIRE(!(d.a_kcontig == 0 && d.b_kcontig == 1), "mmfm_gemm: layout (A row-contig, B k-contig) is not built");
-    MMFM_REQUIRE(d.act >= 0 && d.act <= 4, "mmfm_gemm: bad act %d", d.act);
-    MMFM_REQUIRE(!d.gradmul_pre || d.act == 3 || d.act == 4, "mmfm_gemm: gradmul_pre needs act 3 (gelu') or 4 (softsign')");
+    MMFM_REQUIRE(d.act >= 0 && d.act <= 5, "mmfm_gemm: bad act %d", d.act);
+    MMFM_REQUIRE(!d.gradmul_pre || d.act >= 3, "mmfm_gemm: gradmul_pre needs act 3 (gelu'), 4 (softsign') or 5 (softsign' from the output)");
     MMFM_REQUIRE(d.gradmul_pre || d.act <= 2, "mmfm_gemm: act %d needs gradmul_pre", d.act);
     if (d.splits <= 1) {
         d.splits = 1;

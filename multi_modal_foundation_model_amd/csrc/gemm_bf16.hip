@@ -120,7 +120,7 @@ __device__ __forceinline__ void epilogue_store(const mmfm_gemm_desc& d, const Dr
     else if (d.act == 2) v = softsign_f(v) * d.act_scale;
     if (d.gradmul_pre) {
         const float u = I16::ld(reinterpret_cast<const uint16_t*>(d.gradmul_pre) + (size_t)m * d.ldc + n);
-        v *= (d.act == 3) ? gelu_poly_grad(u) : softsign_grad(u) * d.act_scale;
+        v *= (d.act == 3) ? gelu_poly_grad(u) : (d.act == 4 ? softsign_grad(u) : softsign_grad_from_out(u, 1.f / d.act_scale)) * d.act_scale;
     }
     v = dr.apply(v, (uint64_t)m * (uint64_t)d.N + (uint64_t)n);
     if (d.residual) v += I16::ld(reinterpret_cast<const uint16_t*>(d.residual) + (size_t)m * d.ldr + n);
@@ -257,9 +257,13 @@ __device__ __forceinline__ void epilogue_tile(const mmfm_gemm_desc& d, f32x16 (&
                     float u[8];
                     unpack8(gu[c], u);
                     if (d.act == 3) mul_gelu_grad_n<8>(v, u);
-                    else {
+                    else if (d.act == 4) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) v[e] *= softsign_grad(u[e]) * d.act_scale;
+                    } else {
+                        const float inv_s = 1.f / d.act_scale;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] *= softsign_grad_from_out(u[e], inv_s) * d.act_scale;
                     }
                 }
                 if (dr.on()) {

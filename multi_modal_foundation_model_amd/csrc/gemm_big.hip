@@ -221,12 +221,16 @@ __global__ __launch_bounds__(NT, 2) void gemm_big_kernel(const BigArgs a) {
                                 uu = gelu_grad2(uu);
                                 v[r] *= uu.x; v[r + 1] *= uu.y;
                             }
-                        } else {
+                        } else if (d.act == 4) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
                                 const float rd = __builtin_amdgcn_rcpf(1.f + fabsf(u[r]));
                                 v[r] *= rd * rd * d.act_scale;
                             }
+                        } else {
+                            const float inv_s = 1.f / d.act_scale;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) v[r] *= softsign_grad_from_out(u[r], inv_s) * d.act_scale;
                         }
                     }
                 }

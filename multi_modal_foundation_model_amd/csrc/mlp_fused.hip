@@ -41,138 +41,19 @@ namespace {
 
 constexpr int NT = 256, NW = 4;
 
-__global__ __launch_bounds__(NT) void mlp_fwd_kernel(const mmfm_mlp_desc d) {
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + NW * STG_BYTES + 768 * 4];
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
-    const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
-    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
-    if (my_passes == 0) return;
-    const uint16_t* Wup = reinterpret_cast<const uint16_t*>(d.w_up);
-    const uint16_t* Wdn = reinterpret_cast<const uint16_t*>(d.w_down);
-    const int rot = d.rotate ? (int)(blockIdx.x & 15) : 0;
-    // software pipeline: the up-projection of tile k+1 is multiplied WHILE the GELU of tile k runs on the vector unit (one wave
-    // per SIMD: the only MFMA / VALU overlap there is, is inside the wave's own instruction stream).  Chunk order per pass:
-    //   up(0) | up(1) down(0) | up(2) down(1) | ... | up(15) down(14) | down(15)
-    auto src = [=](int g) {
-        const int idx = g & 31;
-        const bool is_up = idx == 0 || (idx < 31 && (idx & 1));
-        const int k = idx == 0 ? 0 : (idx == 31 ? 15 : (is_up ? (idx + 1) >> 1 : (idx >> 1) - 1));
-        const int tt = (k + rot) & 15;
-        WChunk c;
-        if (!is_up) { c.base = Wdn + 32 * tt; c.ld = 512; c.kind = 2; }
-        else { c.base = Wup + (size_t)(32 * tt) * 256; c.ld = 256; c.kind = 0; }
-        return c;
-    };
-    char* stg = smem + LDS_BYTES + wave * STG_BYTES;
-    float* lb_up = reinterpret_cast<float*>(smem + LDS_BYTES + NW * STG_BYTES);
-    float* lb_dn = lb_up + 512;
-    stage_vec(lb_up, d.b_up, 512, t, NT);
-    stage_vec(lb_dn, d.b_down, 256, t, NT);
-    const Drop dr = drop_init(d.drop);
-    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4);
-    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2;
-    RINGD_DECL(NT);
-    RINGD_START(smem, my_passes * 32, src);
-    STAMP_DECL;
-    for (int pi = 0; pi < my_passes; ++pi) {
-        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
-        const uint32_t row = wrow0 + m;
-        opnd x[16];
-        load_rows_lines<4>(stg, x, X, wrow0, ldxb, lane, m, h);
-        const float rs = ln_rows(x, d.eps);
-        store_rows_lines<4, true>(stg, XH, wrow0, 512u, lane, m, h, x);
-        st4f(RS, h == 0 ? row * 4u : 0xfffffff0u, rs);
-        f32x16 Y8[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Y8[i] = zero16();
-        const char* slot;
-        STAMP(0);
-        RINGD_STEP_E(src, slot);
-        STAMP(1);
-        f32x16 U = mma16<4>(slot, x, zero16(), m, h);                  // up(0)
-        asm volatile("" :: "v"(U[0]));
-        STAMP(2);
-        for (int k = 0; k < 16; ++k) {
-            const int tt = (k + rot) & 15;
-            add_vec(U, lb_up, tt, h);
-            f32x16 Un = zero16();
-            if (k < 15) {                                               // up(k+1) interleaved with gelu(k), element by element
-                RINGD_STEP_O(src, slot);
-                STAMP(1);
-                opnd wf[4];
-#pragma unroll
-                for (int part = 0; part < 4; ++part) {
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) wf[s] = wfragA(slot, 4 * part + s, m, h);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) {
-                        Un = mfma(wf[s], x[4 * part + s], Un);
-                        if (s & 1) gelu_pair(U, 4 * part + s - 1);
-                    }
-                }
-                // hipcc clusters the 16 MFMAs and runs the GELU behind them; pin the interleave: per MFMA one LDS read, the
-                // ~18 vector + 2 transcendental instructions of one GELU (cdna_hip_programming.md T19)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 18, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-                }
-            } else {
-                gelu16(U);
-            }
-            opnd g0, g1;
-            acc_to_opnd(U, g0, g1);
-            asm volatile("" :: "v"(Un[0]), "v"(g0[0]));
-            STAMP(3);
-            if (k < 15) RINGD_STEP_E(src, slot); else RINGD_STEP_O(src, slot);      // down(k): chunk 2k+2, the last one is chunk 31
-            STAMP(4);
-#pragma unroll
-            for (int t2 = 0; t2 < 8; ++t2) {
-                Y8[t2] = mfma(wfragB(slot, t2, 0, m, h), g0, Y8[t2]);
-                Y8[t2] = mfma(wfragB(slot, t2, 1, m, h), g1, Y8[t2]);
-            }
-            asm volatile("" :: "v"(Y8[7][0]));
-            STAMP(5);
-            U = Un;
-        }
-        Lines xl4[4];                                                   // all four residual line groups in flight at once
-#pragma unroll
-        for (int tp = 0; tp < 4; ++tp) xl4[tp] = fetch_lines(X, wrow0, ldxb, 128u * tp, lane);
-#pragma unroll
-        for (int tp = 0; tp < 4; ++tp) {
-            stage_lines(stg, xl4[tp], lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int t2 = 2 * tp + j;
-                add_vec(Y8[t2], lb_dn, t2, h);
-                if (dr.on()) {
-                    drop16(dr, Y8[t2], row, t2, h);
-                }
-                const f32x16 r = unstage_tile(stg, j, m, h);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) Y8[t2][i] += r[i];
-            }
-            stage_tile(stg, 0, m, h, Y8[2 * tp]);
-            stage_tile(stg, 1, m, h, Y8[2 * tp + 1]);
-            flush_lines<false>(stg, Y, wrow0, ldyb, 128u * tp, lane);
-        }
-        STAMP(6);
-    }
-    STAMP_FLUSH;
-}
-
 // MMFM_PROBE (diagnostic builds only, scripts/probe/build_probe.sh): bit 0 drops the g / du stores of the loop, bit 1 the GELU algebra
 #ifndef MMFM_PROBE
 #define MMFM_PROBE 0
 #endif
 __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + 3 * NW * STG_BYTES + 512 * 4];
+    // + a 16 KB per-wave stash of the pass's x_hat rows (four [32 rows][128 B] staging images): the LayerNorm-backward epilogue reads
+    // x_hat twice more, and fetching it from memory again put two more dependent round trips (and 210 MB) into every pass
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + 3 * NW * STG_BYTES + 512 * 4 + NW * 4 * STG_BYTES];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
     const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
     const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
     if (my_passes == 0) return;
+    char* xstash = smem + LDS_BYTES + 3 * NW * STG_BYTES + 512 * 4 + wave * 4 * STG_BYTES;
     const uint16_t* Wup = reinterpret_cast<const uint16_t*>(d.w_up);
     const uint16_t* WdnT = reinterpret_cast<const uint16_t*>(d.w_down_t);
     const uint16_t* WupT = reinterpret_cast<const uint16_t*>(d.w_up_t);
@@ -201,7 +82,17 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
         const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
         const uint32_t row = wrow0 + m;
         opnd x[16], t1[16];
-        load_rows_lines<4>(stg, x, XH, wrow0, 512u, lane, m, h);
+        {   // x_hat: fetched as whole lines into the stash (which doubles as the transposition area for the operand reads) and kept
+            Lines L[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) L[q] = fetch_lines(XH, wrow0, 512u, 128u * q, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                stage_lines(xstash + q * STG_BYTES, L[q], lane);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) x[4 * q + s4] = unstage_opnd(xstash + q * STG_BYTES, s4, m, h);
+            }
+        }
         load_rows_lines<4>(stg, t1, DY, wrow0, lddyb, lane, m, h);
         const float rs = ld4f(RS, row * 4u);
         if (dr.on()) {                                      // dropout'(dy): counter row*256 + k, k = 16s + 8h + j
@@ -251,15 +142,17 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
             }
             STAMP(5);
         }
-        // LayerNorm backward on the row: dx = dy + rstd * (dh - mean(dh) - x_hat * mean(dh * x_hat))
+        // LayerNorm backward on the row: dx = dy + rstd * (dh - mean(dh) - x_hat * mean(dh * x_hat)); x_hat out of the stash, the four
+        // dy line groups requested up front (the operand registers of the loop are dead here)
+        Lines rl4[4];
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) rl4[tp] = fetch_lines(DY, wrow0, lddyb, 128u * tp, lane);
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) {
-            const Lines xl = fetch_lines(XH, wrow0, 512u, 128u * tp, lane);
-            stage_lines(stg, xl, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const f32x16 xt = unstage_tile(stg, j, m, h);
+                const f32x16 xt = unstage_tile(xstash + tp * STG_BYTES, j, m, h);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { s1 += DH[2 * tp + j][i]; s2 = fmaf(DH[2 * tp + j][i], xt[i], s2); }
             }
@@ -268,17 +161,14 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
         s2 = xhalf(s2) * (1.f / 256.f);
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) {
-            const Lines xl = fetch_lines(XH, wrow0, 512u, 128u * tp, lane);
-            const Lines rl = fetch_lines(DY, wrow0, lddyb, 128u * tp, lane);
-            stage_lines(stg, xl, lane);
             f32x16 o[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const f32x16 xt = unstage_tile(stg, j, m, h);
+                const f32x16 xt = unstage_tile(xstash + tp * STG_BYTES, j, m, h);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[j][i] = rs * (DH[2 * tp + j][i] - s1 - xt[i] * s2);
             }
-            stage_lines(stg, rl, lane);
+            stage_lines(stg, rl4[tp], lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const f32x16 r = unstage_tile(stg, j, m, h);
@@ -295,15 +185,11 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
 }
 
 // ------------------------------------------------------------------------------------------------ wave-pair versions
-// The one-wave-per-row-tile kernels above need ~450 registers (one wave per SIMD, operands bouncing through the accumulator
-// file, GELU serialised with the MFMAs).  Here waves w and w+4 own the SAME 32 rows and split the work, so each fits 256
-// registers and every SIMD runs two waves (VALU of one beside MFMAs of the other, vector issue at the two-wave rate):
-//   forward : both hold x_hat; wave A takes intermediate tiles 2u, wave B 2u+1 (up-projection + GELU), they swap the bf16
-//             operands of g through LDS, and each accumulates HALF of the 256 output columns over all of g.
-//   backward: A holds x_hat and recomputes u (both tiles of a pair), B holds t1 = dropout'(dy) and computes dg; A hands
-//             gelu'(u) to B, B forms du and hands its operands back; each accumulates half of d(x_hat); the LayerNorm
-//             backward sums its row statistics across the pair.
-// Chunks are 32 KB (two 16 KB sub-blocks, one per role or one per intermediate tile of the pair).
+// Forward: waves w and w+4 own the SAME 32 rows and split the work, so each fits 256 registers and every SIMD runs two waves
+// (VALU of one beside MFMAs of the other): both hold x_hat; wave A takes intermediate tiles 2u, wave B 2u+1 (up-projection + GELU),
+// they swap the bf16 operands of g through LDS, and each accumulates HALF of the 256 output columns over all of g.  Chunks are
+// 32 KB (two 16 KB sub-blocks, one per intermediate tile of the pair).  (Measured and no longer compiled - DESIGN.md section 3b: a
+// one-wave-per-tile forward, 300 us against 257 us, and a wave-pair backward, 539 us against 478 us for the one-wave kernel above.)
 constexpr int NT8 = 512;
 
 __global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
@@ -400,163 +286,6 @@ __global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
     }
 }
 
-__global__ __launch_bounds__(NT8) void mlp_bwd8_kernel(const mmfm_mlp_desc d) {
-    constexpr int NPAIR = 4;
-    __shared__ __attribute__((aligned(16))) char smem[2 * CHUNK2 + 8 * STG_BYTES + NPAIR * 4096 + 8 * 32 * 8 + 512 * 4];
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
-    const int role = wave >> 2, pw = wave & 3;
-    const int64_t npass = (d.R + 32 * NPAIR - 1) / (32 * NPAIR);
-    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
-    if (my_passes == 0) return;
-    const uint16_t* Wup = reinterpret_cast<const uint16_t*>(d.w_up);
-    const uint16_t* WdnT = reinterpret_cast<const uint16_t*>(d.w_down_t);
-    const uint16_t* WupT = reinterpret_cast<const uint16_t*>(d.w_up_t);
-    const int rot = d.rotate ? (int)(blockIdx.x & 7) : 0;
-    auto src = [=](int g) {                              // per pair of intermediate tiles (2u, 2u+1): three chunks
-        const int idx = g % 24, ui = idx / 3, k = idx - 3 * ui, u = (ui + rot) & 7;
-        WChunk2 c;
-        if (k < 2) {                                     // tile 2u + k: [Wp_up rows (recompute, role A) | W_down^T rows (dg, role B)]
-            c.s[0].base = Wup + (size_t)(32 * (2 * u + k)) * 256; c.s[0].ld = 256; c.s[0].kind = 0;
-            c.s[1].base = WdnT + (size_t)(32 * (2 * u + k)) * 256; c.s[1].ld = 256; c.s[1].kind = 0;
-        } else {                                         // Wp_up^T columns of the two tiles (d x_hat += du . Wp_up)
-            c.s[0].base = WupT + 64 * u; c.s[0].ld = 512; c.s[0].kind = 2;
-            c.s[1].base = WupT + 64 * u + 32; c.s[1].ld = 512; c.s[1].kind = 2;
-        }
-        return c;
-    };
-    char* stg = smem + 2 * CHUNK2 + wave * STG_BYTES;
-    char* exch = smem + 2 * CHUNK2 + 8 * STG_BYTES + pw * 4096;            // 4 x [64 lanes][16 B]: gelu'(u) (A->B), then du operands (B->A)
-    float2* sx = reinterpret_cast<float2*>(smem + 2 * CHUNK2 + 8 * STG_BYTES + NPAIR * 4096);      // [wave][32 rows]
-    float* lb_up = reinterpret_cast<float*>(smem + 2 * CHUNK2 + 8 * STG_BYTES + NPAIR * 4096 + 8 * 32 * 8);
-    stage_vec(lb_up, d.b_up, 512, t, NT8);
-    const Drop dr = drop_init(d.drop);
-    const GBuf XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4), DY = gbuf(d.dy, d.R * d.lddy * 2);
-    const GBuf T1 = gbuf(role == 1 ? d.t1 : nullptr, d.R * 512);
-    const GBuf GD = gbuf(role == 0 ? d.g : d.du, d.R * 1024), DX = gbuf(d.dx, d.R * d.lddx * 2);
-    const uint32_t lddyb = d.lddy * 2, lddxb = d.lddx * 2;
-    RING2_DECL(NT8);
-    RING2_START(smem, my_passes * 24, src);
-    for (int pi = 0; pi < my_passes; ++pi) {
-        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NPAIR + pw) * 32);
-        const uint32_t row = wrow0 + m;
-        opnd x[16];                                      // role A: x_hat;  role B: t1 = dropout'(dy)
-        if (role == 0) load_rows_lines<4>(stg, x, XH, wrow0, 512u, lane, m, h);
-        else {
-            load_rows_lines<4>(stg, x, DY, wrow0, lddyb, lane, m, h);
-            if (dr.on()) {                               // counter row*256 + k, k = 16s + 8h + j
-#pragma unroll
-                for (int s = 0; s < 16; ++s) {
-                    float f[8]; unpack8f(x[s], f);
-                    drop8(dr, f, row, 16 * s + 8 * h);
-                    x[s] = pack8o(f);
-                }
-            }
-            store_rows_lines<4, true>(stg, T1, wrow0, 512u, lane, m, h, x);
-        }
-        f32x16 DH[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) DH[i] = zero16();
-        for (int ui = 0; ui < 8; ++ui) {
-            const int u = (ui + rot) & 7;
-            const char* slot;
-            f32x16 A2[2];                                // role A: u of tiles 2u, 2u+1;  role B: dg of the same tiles
-            RING2_STEP(src, slot);
-            A2[0] = mma16<4>(slot + role * CHUNK, x, zero16(), m, h);
-            RING2_STEP(src, slot);
-            A2[1] = mma16<4>(slot + role * CHUNK, x, zero16(), m, h);
-            if (role == 0) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    add_vec(A2[j], lb_up, 2 * u + j, h);
-                    uint32_t gp[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        mmfm_f32x2 a; a.x = A2[j][2 * i]; a.y = A2[j][2 * i + 1];
-                        a = gelu_grad2(a);
-                        gp[i] = pack2(a.x, a.y);
-                    }
-                    *reinterpret_cast<uint4*>(exch + (2 * j) * 1024 + lane * 16) = make_uint4(gp[0], gp[1], gp[2], gp[3]);
-                    *reinterpret_cast<uint4*>(exch + (2 * j + 1) * 1024 + lane * 16) = make_uint4(gp[4], gp[5], gp[6], gp[7]);
-                }
-            }
-            __syncthreads();                             // gelu'(u) of the pair visible to B
-            opnd du[4];
-            if (role == 1) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const uint4 a = *reinterpret_cast<const uint4*>(exch + (2 * j) * 1024 + lane * 16);
-                    const uint4 b = *reinterpret_cast<const uint4*>(exch + (2 * j + 1) * 1024 + lane * 16);
-                    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { A2[j][2 * i] *= lo_f(w[i]); A2[j][2 * i + 1] *= hi_f(w[i]); }
-                    acc_to_opnd(A2[j], du[2 * j], du[2 * j + 1]);
-                }
-            } else {
-                gelu16(A2[0]);
-                gelu16(A2[1]);
-            }
-            // both roles: their tile pair (A: g, B: du) leaves as whole lines of the [R][512] tensor
-            stage_tile(stg, 0, m, h, A2[0]);
-            stage_tile(stg, 1, m, h, A2[1]);
-            flush_lines<true>(stg, GD, wrow0, 1024u, 128u * u, lane);
-            __syncthreads();                             // every B has read gelu'(u): the exchange area is free again
-            if (role == 1) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(exch + i * 1024 + lane * 16) = as_u4(du[i]);
-            }
-            RING2_STEP(src, slot);                       // its barrier publishes du's operands
-            if (role == 0) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) du[i] = as_opnd(*reinterpret_cast<const uint4*>(exch + i * 1024 + lane * 16));
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t2 = 4 * role + j;
-                DH[j] = mfma(wfragB(slot, t2, 0, m, h), du[0], DH[j]);
-                DH[j] = mfma(wfragB(slot, t2, 1, m, h), du[1], DH[j]);
-                DH[j] = mfma(wfragB(slot + CHUNK, t2, 0, m, h), du[2], DH[j]);
-                DH[j] = mfma(wfragB(slot + CHUNK, t2, 1, m, h), du[3], DH[j]);
-            }
-        }
-        // LayerNorm backward: this wave's half of the columns (line pairs 2*role, 2*role+1), statistics summed over the pair
-        f32x16 xt[4];
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const Lines xl = fetch_lines(XH, wrow0, 512u, 128u * (2 * role + q), lane);
-            stage_lines(stg, xl, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                xt[2 * q + j] = unstage_tile(stg, j, m, h);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) { s1 += DH[2 * q + j][i]; s2 = fmaf(DH[2 * q + j][i], xt[2 * q + j][i], s2); }
-            }
-        }
-        s1 = xhalf(s1); s2 = xhalf(s2);
-        if (h == 0) sx[wave * 32 + m] = make_float2(s1, s2);
-        __syncthreads();
-        const float2 o2 = sx[(wave ^ 4) * 32 + m];
-        s1 = (s1 + o2.x) * (1.f / 256.f);
-        s2 = (s2 + o2.y) * (1.f / 256.f);
-        const float rs = ld4f(RS, row * 4u);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const Lines rl = fetch_lines(DY, wrow0, lddyb, 128u * (2 * role + q), lane);
-            stage_lines(stg, rl, lane);
-            f32x16 o[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x16 r = unstage_tile(stg, j, m, h);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) o[j][i] = r[i] + rs * (DH[2 * q + j][i] - s1 - xt[2 * q + j][i] * s2);
-            }
-            stage_tile(stg, 0, m, h, o[0]);
-            stage_tile(stg, 1, m, h, o[1]);
-            flush_lines<false>(stg, DX, wrow0, lddxb, 128u * (2 * role + q), lane);
-        }
-    }
-}
-
 // dW = gamma * G + db x beta; dgamma = colsum(W * G); dbeta = W^T db.  Grid (K/32 column groups) x (NSPLIT row groups): every
 // block writes its dW rows and a partial (dgamma, dbeta) row; the LAST block of a column group (agent-scope ticket) sums the
 // NSPLIT partials in fixed order -> deterministic, one launch.
@@ -638,10 +367,7 @@ extern "C" int mmfm_mlp_fwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     const mmfm_mlp_desc d = *dp;
     if (int rc = check(d, false)) return rc;
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
-    // measured in the B = 1024 step (p = 0.4): wave-pair forward 257 us, one-wave forward 300 us -> pairs by default
-    static const int v1 = [] { const char* e = getenv("MMFM_MLP_FWD_V1"); return e ? atoi(e) : 0; }();
-    if (!v1) hipLaunchKernelGGL(mlp_fwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), 0, (hipStream_t)stream, d);
-    else hipLaunchKernelGGL(mlp_fwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(mlp_fwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), 0, (hipStream_t)stream, d);
     MMFM_LAUNCH_CHECK("mmfm_mlp_fwd");
     return 0;
 }
@@ -650,10 +376,7 @@ extern "C" int mmfm_mlp_bwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     const mmfm_mlp_desc d = *dp;
     if (int rc = check(d, true)) return rc;
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
-    // ... and the backward the other way round: one wave per tile 478 us, wave pairs 539 us -> one-wave by default
-    static const int v1 = [] { const char* e = getenv("MMFM_MLP_BWD_V1"); return e ? atoi(e) : 1; }();
-    if (!v1) hipLaunchKernelGGL(mlp_bwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), 0, (hipStream_t)stream, d);
-    else hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), 0, (hipStream_t)stream, d);
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), 0, (hipStream_t)stream, d);
     MMFM_LAUNCH_CHECK("mmfm_mlp_bwd");
     return 0;
 }

@@ -232,53 +232,6 @@ __device__ __forceinline__ void stage_write2(const uint4 (&r)[2048 / NT], const 
     } while (0)
 #define RING2_STEP(SRC, SLOT) do { RING2_SYNC_WRITE(SRC); RING2_FETCH(SRC, SLOT); } while (0)
 
-// ---- the weight stream as ONE dedicated wave ------------------------------------------------------------------------
-// s_waitcnt vmcnt retires IN ORDER, so a wave that has an HBM load in flight (its next activation rows, a residual tile)
-// cannot wait for a younger L2-hit weight chunk without also waiting out the HBM latency: in the versions where every wave
-// staged weights, each activation prefetch stalled the ring for 2-3 us (measured: 60 % of the LayerNorm-backward kernel).
-// So one wave of the workgroup does nothing but stream weights - three 16 KB chunks in flight in its own registers, written
-// to the two-slot LDS ring one step ahead of the consumers - and the compute waves never wait on a weight load: they only
-// meet the stager at the per-chunk barrier.  The stager runs `total` steps, each ending in the barrier that publishes its
-// chunk; `SRC(g)` as above.
-// one wave issues the 16 loads of a chunk: a single buffer descriptor + scalar offsets (48 flat addresses in flight at once
-// would not fit the register file next to the 192 data registers)
-__device__ __forceinline__ void ws_issue(uint4 (&r)[16], const WChunk& c, int lane) {
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(c.base), 0, 0x7fffffff, 0x00020000);
-    const int ldb = c.ld * 2;
-    if (c.kind == 2) {                                   // [256 rows][32 k]: piece p = lane + 64 q -> row 16 q + lane / 4, col lane % 4
-        const int v0 = (lane >> 2) * ldb + (lane & 3) * 16;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) r[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, v0, q * 16 * ldb, 0));
-    } else {                                             // [32 rows][256 k]: row 2 q + lane / 32, col lane % 32
-        const int v0 = (lane >> 5) * ldb + (lane & 31) * 16;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) r[q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rs, v0, q * 2 * ldb, 0));
-    }
-}
-template <class Src>
-__device__ __forceinline__ void weight_stager(char* smem, int total, Src&& src, int lane) {
-    uint4 r0[16], r1[16], r2[16];                    // three chunks in flight, statically named (no scratch)
-    const int last = total - 1;
-    ws_issue(r0, src(0), lane); ws_issue(r1, src(min(1, last)), lane); ws_issue(r2, src(min(2, last)), lane);
-    for (int g = 0; g < total; g += 3) {
-        stage_write<64>(r0, src(min(g, last)).kind, smem + (g & 1) * CHUNK, lane);
-        ws_issue(r0, src(min(g + 3, last)), lane);
-        __syncthreads();
-        if (g + 1 < total) {
-            stage_write<64>(r1, src(min(g + 1, last)).kind, smem + ((g + 1) & 1) * CHUNK, lane);
-            ws_issue(r1, src(min(g + 4, last)), lane);
-            __syncthreads();
-        }
-        if (g + 2 < total) {
-            stage_write<64>(r2, src(min(g + 2, last)).kind, smem + ((g + 2) & 1) * CHUNK, lane);
-            ws_issue(r2, src(min(g + 5, last)), lane);
-            __syncthreads();
-        }
-    }
-}
-// consumer side of a step: wait for the stager's chunk g, return its slot
-#define WS_STEP(SLOT, G) do { __syncthreads(); SLOT = ws_smem + ((G) & 1) * CHUNK; ++(G); } while (0)
-
 // weight operand of k-step S (0..15) from a [32][256] image: lane (i = lane & 31, h = lane >> 5)
 __device__ __forceinline__ opnd wfragA(const char* slot, int S, int i, int h) {
     return as_opnd(*reinterpret_cast<const uint4*>(slot + i * 512 + (((2 * S + h) ^ (i & 15)) << 4)));

@@ -96,173 +96,6 @@ __global__ __launch_bounds__(NWV * 64, (KP == 1 ? 2 : 1)) void rowgemm_kernel(co
     }
 }
 
-// ------------------------------------------------------------------------------------------------ K = 256, eight waves, skewed
-// The K = 256 products (ln1+qkv, query, key/value, context projection, out_proj and its dX) as ONE 512-thread workgroup per
-// CU: 32 KB chunks (a pair of 32-row weight tiles = 32 MFMAs per wave per barrier) and the two wave groups SKEWED by half a
-// step - waves 0-3 multiply chunk c and then run its epilogue, waves 4-7 run the epilogue of chunk c-1 and then multiply
-// chunk c - so that on every SIMD one wave's MFMAs run beside its partner's epilogue (VALU + LDS staging + stores) instead
-// of both waves idling the matrix pipe together (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
-template <bool LN, bool NTS, bool HAS_RES>
-__global__ __launch_bounds__(512) void rowgemm8_kernel(const mmfm_rowgemm_desc d) {
-    constexpr int NT = 512, NW = 8;
-    __shared__ __attribute__((aligned(16))) char smem[2 * CHUNK2 + NW * STG_BYTES + BIAS_MAX * 4];
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
-    const int npair = d.N >> 6;
-    const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
-    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
-    if (my_passes == 0) return;
-    const uint16_t* W = reinterpret_cast<const uint16_t*>(d.w);
-    const int ldw = d.ldw;
-    const int rot = d.rotate ? (int)(blockIdx.x % npair) : 0;
-    auto src = [=](int g) {
-        int pr = g % npair + rot; pr = pr >= npair ? pr - npair : pr;
-        WChunk2 c;
-        c.s[0].base = W + (size_t)(64 * pr) * ldw; c.s[0].ld = ldw; c.s[0].kind = 0;
-        c.s[1].base = W + (size_t)(64 * pr + 32) * ldw; c.s[1].ld = ldw; c.s[1].kind = 0;
-        return c;
-    };
-    char* stg = smem + 2 * CHUNK2 + wave * STG_BYTES;
-    float* lbias = reinterpret_cast<float*>(smem + 2 * CHUNK2 + NW * STG_BYTES);
-    stage_vec(lbias, d.bias, d.N, t, NT);
-    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), RES = gbuf(d.residual, d.R * d.ldr * 2);
-    const GBuf XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4);
-    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2, ldrb = d.ldr * 2;
-    const bool late = wave >= 4;                         // wave-uniform: this group's epilogue trails its MFMAs by one step
-    RING2_DECL(NT);
-    RING2_START(smem, my_passes * npair, src);
-    auto epilogue = [&](f32x16 (&acc)[2], int pr, uint32_t wrow0, const Lines& res) {
-        add_vec(acc[0], lbias, 2 * pr, h);
-        add_vec(acc[1], lbias, 2 * pr + 1, h);
-        if constexpr (HAS_RES) {
-            stage_lines(stg, res, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const f32x16 r = unstage_tile(stg, j, m, h);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[j][i] += r[i];
-            }
-        }
-        stage_tile(stg, 0, m, h, acc[0]);
-        stage_tile(stg, 1, m, h, acc[1]);
-        flush_lines<NTS>(stg, Y, wrow0, ldyb, 128u * pr, lane);
-    };
-    for (int pi = 0; pi < my_passes; ++pi) {
-        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
-        const bool live = wrow0 < (uint32_t)d.R;          // a wave without rows only keeps the ring's barriers
-        opnd x[16];
-        if (live) load_rows_lines<4>(stg, x, X, wrow0, ldxb, lane, m, h);
-        if constexpr (LN) if (live) {
-            const float rs = ln_rows(x, d.eps);
-            store_rows_lines<4, true>(stg, XH, wrow0, 512u, lane, m, h, x);
-            st4f(RS, h == 0 ? (wrow0 + m) * 4u : 0xfffffff0u, rs);
-        }
-        f32x16 acc[2];                                    // late group: holds the previous step's tile pair until its epilogue
-        int prp = 0;
-        for (int tp = 0; tp < npair; ++tp) {
-            int pr = tp + rot; pr = pr >= npair ? pr - npair : pr;
-            RING2_SYNC_WRITE(src);
-            Lines res;
-            if constexpr (HAS_RES) res = fetch_lines(RES, wrow0, ldrb, 128u * (late ? prp : pr), lane);
-            const char* slot;
-            RING2_FETCH(src, slot);
-            if (!live) continue;
-            if (late && tp > 0) epilogue(acc, prp, wrow0, res);
-            acc[0] = mma16<4>(slot, x, zero16(), m, h);
-            acc[1] = mma16<4>(slot + CHUNK, x, zero16(), m, h);
-            if (!late) epilogue(acc, pr, wrow0, res);
-            prp = pr;
-        }
-        if (late && live) {
-            Lines res;
-            if constexpr (HAS_RES) res = fetch_lines(RES, wrow0, ldrb, 128u * prp, lane);
-            epilogue(acc, prp, wrow0, res);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------ K = 256, stager wave + 7 compute waves
-template <bool LN, bool NTS, bool HAS_RES>
-__global__ __launch_bounds__(512) void rowgemm7_kernel(const mmfm_rowgemm_desc d) {
-    constexpr int NC = 7;                                // compute waves (32 rows each); wave 7 streams the weights
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + NC * STG_BYTES + BIAS_MAX * 4];
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
-    const int ntile = d.N >> 5, npair = d.N >> 6;
-    const int64_t npass = (d.R + 32 * NC - 1) / (32 * NC);
-    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
-    if (my_passes == 0) return;
-    const uint16_t* W = reinterpret_cast<const uint16_t*>(d.w);
-    const int ldw = d.ldw;
-    const int rot = d.rotate ? (int)(blockIdx.x % npair) : 0;
-    auto src = [=](int g) {
-        const int ti = g % ntile;
-        int pr = (ti >> 1) + rot; pr = pr >= npair ? pr - npair : pr;
-        WChunk c;
-        c.base = W + (size_t)(32 * (2 * pr + (ti & 1))) * ldw; c.ld = ldw; c.kind = 0;
-        return c;
-    };
-    float* lbias = reinterpret_cast<float*>(smem + LDS_BYTES + NC * STG_BYTES);
-    stage_vec(lbias, d.bias, d.N, t, 512);              // visible after the first step's barrier
-    if (wave == NC) { weight_stager(smem, my_passes * ntile, src, lane); return; }
-    char* ws_smem = smem;
-    char* stg = smem + LDS_BYTES + wave * STG_BYTES;
-    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), RES = gbuf(d.residual, d.R * d.ldr * 2);
-    const GBuf XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4);
-    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2, ldrb = d.ldr * 2;
-    int g = 0;
-    uint32_t wrow0 = (uint32_t)(((int64_t)blockIdx.x * NC + wave) * 32);
-    Lines L[4];                                          // the NEXT pass's rows, in flight during this pass's products
-#pragma unroll
-    for (int q = 0; q < 4; ++q) L[q] = fetch_lines(X, wrow0, ldxb, 128u * q, lane);
-    for (int pi = 0; pi < my_passes; ++pi) {
-        const bool live = wrow0 < (uint32_t)d.R;
-        const uint32_t nrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)(pi + 1) * gridDim.x) * NC + wave) * 32);
-        opnd x[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            stage_lines(stg, L[q], lane);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4) x[4 * q + s4] = unstage_opnd(stg, s4, m, h);
-            L[q] = fetch_lines(X, nrow0, ldxb, 128u * q, lane);          // beyond the tensor: reads as zero, costs nothing
-        }
-        if constexpr (LN) {
-            const float rs = ln_rows(x, d.eps);
-            store_rows_lines<4, true>(stg, XH, wrow0, 512u, lane, m, h, x);
-            st4f(RS, h == 0 ? (wrow0 + m) * 4u : 0xfffffff0u, rs);
-        }
-        Lines res;
-        if constexpr (HAS_RES) { int pr0 = rot; res = fetch_lines(RES, wrow0, ldrb, 128u * pr0, lane); }
-        for (int tp = 0; tp < npair; ++tp) {
-            int pr = tp + rot; pr = pr >= npair ? pr - npair : pr;
-            int prn = pr + 1; prn = prn >= npair ? prn - npair : prn;
-            f32x16 acc[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const char* slot;
-                WS_STEP(slot, g);
-                acc[j] = zero16();
-                if (live) acc[j] = mma16<4>(slot, x, acc[j], m, h);
-            }
-            if (!live) continue;
-            add_vec(acc[0], lbias, 2 * pr, h);
-            add_vec(acc[1], lbias, 2 * pr + 1, h);
-            if constexpr (HAS_RES) {
-                stage_lines(stg, res, lane);
-                if (tp + 1 < npair) res = fetch_lines(RES, wrow0, ldrb, 128u * prn, lane);    // one pair ahead
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const f32x16 r = unstage_tile(stg, j, m, h);
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) acc[j][i] += r[i];
-                }
-            }
-            stage_tile(stg, 0, m, h, acc[0]);
-            stage_tile(stg, 1, m, h, acc[1]);
-            flush_lines<NTS>(stg, Y, wrow0, ldyb, 128u * pr, lane);
-        }
-        wrow0 = nrow0;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ dX + LayerNorm backward
 // v = x . W^T (N = 256: the gradient wrt x_hat of the LayerNorm that fed the forward linear; W = prepared W'^T);
 // y = dres + rstd * (v - mean(v) - x_hat * mean(v * x_hat))
@@ -514,58 +347,34 @@ extern "C" int mmfm_rowgemm(const mmfm_rowgemm_desc* dp, mmfm_stream stream) {
     const int64_t maxld = std::max<int64_t>(std::max(d.ldx, d.ldy), std::max(d.ldr, 256));
     MMFM_REQUIRE((d.R + 128) * maxld * 2 < (int64_t)1 << 31, "mmfm_rowgemm: tensors beyond 2 GiB are not addressable by the 32-bit buffer offsets");
     MMFM_REQUIRE(d.N <= BIAS_MAX, "mmfm_rowgemm: N = %d > %d", d.N, BIAS_MAX);
-    // Variant selection (measured on MI355X at R = 204,800, scripts/rowchain_bench.py):
-    //   forward-type K = 256 : v1 = 4 waves x 2 workgroups per CU (default: LN+q 78 us, LN+kv 117 us, out_proj 71 us);
-    //                          v8 = 8 waves, 32 KB chunks, skewed wave groups; v7 = 7 compute waves + 1 weight-stager wave
+    // Launch shapes (measured on MI355X at R = 204,800, scripts/rowchain_bench.py; the rejected variants - 8 skewed waves, a dedicated
+    // weight-stager wave, 8-wave forward - are described in DESIGN.md section 3b and no longer compiled):
+    //   forward-type : 4 waves, 2 workgroups per CU at K = 256 (LN+q 78 us, LN+kv 117 us, out_proj 71 us), 1 per CU at K = 512 / 768
     //   LN-backward epilogue : K = 256 -> wave pairs (8 waves, 101 us); K = 512 / 768 -> one wave per row tile (172 / 284 us)
     static const int per_cu_env = [] { const char* e = getenv("MMFM_ROWGEMM_WG_PER_CU"); return e ? atoi(e) : 0; }();
-    static const int variant = [] { const char* e = getenv("MMFM_ROWGEMM_VARIANT"); return e ? atoi(e) : 1; }();   // 1, 7, 8 (18 = v1 with 8 waves)
-    static const int lb_pairs = [] { const char* e = getenv("MMFM_LNBWD_PAIRS"); return e ? atoi(e) : 256; }();      // largest K that uses wave pairs
     hipStream_t st = (hipStream_t)stream;
     if (d.ln_bwd) {
         MMFM_REQUIRE(d.N == 256 && d.bwd_xhat && d.bwd_rstd && !d.ln && !d.bias, "mmfm_rowgemm: ln_bwd needs N = 256, x_hat, rstd, no bias/ln");
-        if (d.K <= lb_pairs) {
+        if (d.K == 256) {
             dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, 4)), block(512);      // 4 row tiles (wave pairs) per pass
-            if (d.K == 256) hipLaunchKernelGGL(rowgemm_lnbwd8_kernel<1>, grid, block, 0, st, d);
-            else if (d.K == 512) hipLaunchKernelGGL(rowgemm_lnbwd8_kernel<2>, grid, block, 0, st, d);
-            else hipLaunchKernelGGL(rowgemm_lnbwd8_kernel<3>, grid, block, 0, st, d);
+            hipLaunchKernelGGL(rowgemm_lnbwd8_kernel<1>, grid, block, 0, st, d);
         } else {
             dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1)), block(NT);
-            if (d.K == 256) hipLaunchKernelGGL(rowgemm_lnbwd_kernel<1>, grid, block, 0, st, d);
-            else if (d.K == 512) hipLaunchKernelGGL(rowgemm_lnbwd_kernel<2>, grid, block, 0, st, d);
+            if (d.K == 512) hipLaunchKernelGGL(rowgemm_lnbwd_kernel<2>, grid, block, 0, st, d);
             else hipLaunchKernelGGL(rowgemm_lnbwd_kernel<3>, grid, block, 0, st, d);
         }
     } else {
-#define RG_LAUNCH(KP, LN, NWV)                                                                               \
-    if (d.stream_out) hipLaunchKernelGGL((rowgemm_kernel<KP, LN, true, NWV>), grid, block, 0, st, d);        \
-    else hipLaunchKernelGGL((rowgemm_kernel<KP, LN, false, NWV>), grid, block, 0, st, d);
-#define RG8_LAUNCH(LN, NTS)                                                                                  \
-    if (d.residual) hipLaunchKernelGGL((rowgemm8_kernel<LN, NTS, true>), grid, block, 0, st, d);             \
-    else hipLaunchKernelGGL((rowgemm8_kernel<LN, NTS, false>), grid, block, 0, st, d);
-#define RG7_LAUNCH(LN, NTS)                                                                                  \
-    if (d.residual) hipLaunchKernelGGL((rowgemm7_kernel<LN, NTS, true>), grid, block, 0, st, d);             \
-    else hipLaunchKernelGGL((rowgemm7_kernel<LN, NTS, false>), grid, block, 0, st, d);
+#define RG_LAUNCH(KP, LN)                                                                                   \
+    if (d.stream_out) hipLaunchKernelGGL((rowgemm_kernel<KP, LN, true, 4>), grid, block, 0, st, d);         \
+    else hipLaunchKernelGGL((rowgemm_kernel<KP, LN, false, 4>), grid, block, 0, st, d);
         if (d.K != 256) {
             dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, 4)), block(256);
-            if (d.K == 512) { RG_LAUNCH(2, false, 4) } else { RG_LAUNCH(3, false, 4) }
-        } else if (variant == 7) {
-            dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, 7)), block(512);
-            if (d.ln) { if (d.stream_out) { RG7_LAUNCH(true, true) } else { RG7_LAUNCH(true, false) } }
-            else { if (d.stream_out) { RG7_LAUNCH(false, true) } else { RG7_LAUNCH(false, false) } }
-        } else if (variant == 8) {
-            dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, 8)), block(512);
-            if (d.ln) { if (d.stream_out) { RG8_LAUNCH(true, true) } else { RG8_LAUNCH(true, false) } }
-            else { if (d.stream_out) { RG8_LAUNCH(false, true) } else { RG8_LAUNCH(false, false) } }
-        } else if (variant == 18) {
-            dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1, 8)), block(512);
-            if (d.ln) { RG_LAUNCH(1, true, 8) } else { RG_LAUNCH(1, false, 8) }
+            if (d.K == 512) { RG_LAUNCH(2, false) } else { RG_LAUNCH(3, false) }
         } else {
             dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 2, 4)), block(256);
-            if (d.ln) { RG_LAUNCH(1, true, 4) } else { RG_LAUNCH(1, false, 4) }
+            if (d.ln) { RG_LAUNCH(1, true) } else { RG_LAUNCH(1, false) }
         }
 #undef RG_LAUNCH
-#undef RG8_LAUNCH
-#undef RG7_LAUNCH
     }
     MMFM_LAUNCH_CHECK("mmfm_rowgemm");
     return 0;

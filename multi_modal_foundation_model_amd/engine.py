@@ -556,7 +556,10 @@ class Engine:
             for m, (mod, n) in enumerate(c.mods):
                 p = f"{side}_embeddings.{mod}.embedder"
                 n2 = n * c.mult
-                z, a = buf(f"{side}/z/{m}", (BT, n2)), buf(f"{side}/a/{m}", (BT, n2))
+                a = buf(f"{side}/a/{m}", (BT, n2))
+                # bf16 mode: the backward takes softsign' from the activation itself (act 5), no saved pre-activation (274 MB per
+                # tokeniser at B = 1024, written here and read back there); the fp32 parity path keeps the exact form
+                z = None if code == L.BF16 else buf(f"{side}/z/{m}", (BT, n2))
                 lin(fwd, self.b[f"in/{m}"], p + ".token_embed", a, BT, n2, n, pre_out=z, act=L.ACT_SOFTSIGN, act_scale=c.embed_scale)
                 lin(fwd, a, p + ".projection", tok_tmp, BT, H, n2, drop=self._drop(f"{side}/embdrop/{m}", dpe))
                 mod_row = self.Pf(f"encoder_embeddings.{mod}.embedder.mod_emb.weight")[m]
@@ -758,8 +761,12 @@ class Engine:
                 p = f"{side}_embeddings.{mod}.embedder"
                 n2 = n * c.mult
                 dz = buf(f"d/z/{m}", (BT, n2))
-                dlin(cur, self.b[f"d/tok/{side}/{m}"], self.b[f"{side}/a/{m}"], p + ".projection", BT, H, n2, dX=dz,
-                     act=L.ACT_SOFTSIGN_GRAD, act_scale=c.embed_scale, gradmul_pre=self.b[f"{side}/z/{m}"])
+                if code == L.BF16:
+                    dlin(cur, self.b[f"d/tok/{side}/{m}"], self.b[f"{side}/a/{m}"], p + ".projection", BT, H, n2, dX=dz,
+                         act=L.ACT_SOFTSIGN_GRAD_OUT, act_scale=c.embed_scale, gradmul_pre=self.b[f"{side}/a/{m}"])
+                else:
+                    dlin(cur, self.b[f"d/tok/{side}/{m}"], self.b[f"{side}/a/{m}"], p + ".projection", BT, H, n2, dX=dz,
+                         act=L.ACT_SOFTSIGN_GRAD, act_scale=c.embed_scale, gradmul_pre=self.b[f"{side}/z/{m}"])
                 dlin(cur, dz, self.b[f"in/{m}"], p + ".token_embed", BT, n2, n)
         close_segment("embed")
         if used_wt:                 # refresh the bf16 transposes once per step, in front of everything (the optimiser rewrote the weights)

@@ -481,6 +481,14 @@ def test_gemm_bf16_epilogues_and_layouts(ops, N):
     p32 = pr.float().requires_grad_(True)
     torch.nn.functional.gelu(p32).sum().backward()
     close_bf16(dx, (dy.float() @ w2.float()) * p32.grad, "bf16 dX*gelu'")
+    # act 4 / act 5: softsign' from the saved pre-activation, and from the activation's output (what the bf16 engine keeps)
+    ops.gemm(dy, w2, dx, M, N, K, lda=K, ldb=N, ldc=N, b_kcontig=0, act=4, act_scale=0.7, gradmul_pre=pr)
+    exact = (dy.double() @ w2.double()) * 0.7 / (1 + pr.double().abs()) ** 2
+    close_bf16(dx, exact, "bf16 dX*softsign'")
+    a_out = bf(0.7 * pr.double() / (1 + pr.double().abs()))
+    ops.gemm(dy, w2, dx, M, N, K, lda=K, ldb=N, ldc=N, b_kcontig=0, act=5, act_scale=0.7, gradmul_pre=a_out)
+    close_bf16(dx, (dy.double() @ w2.double()) * 0.7 * (1 - a_out.double().abs() / 0.7) ** 2, "bf16 dX*softsign' from the output")
+    close_bf16(dx, exact, "bf16 dX*softsign' from the output vs exact", tol=2.5e-2)
 
 
 @pytest.mark.parametrize("R,N,K,splits", [(3200, 256, 256, 8), (1000, 668, 256, 4), (777, 1336, 668, 3), (640, 2, 256, 2), (3200, 768, 256, 1), (900, 4, 2, 2)])
@@ -661,6 +669,11 @@ def test_gemm_bf16_256_tile_kernel(ops, M, N, K, Kreal):
     close_bf16(y0, (x.double() @ w.double().T) * gp, "256-tile gelu'")
     ops.gemm(x, w, y0, M, N, K, lda=K, ldb=K, ldc=N, gradmul_pre=u, act=4, act_scale=0.7)
     close_bf16(y0, (x.double() @ w.double().T) * 0.7 / (1 + ud.abs()) ** 2, "256-tile softsign'")
+    # act 5: the same derivative from the activation OUTPUT a = 0.7 softsign(u) (what the bf16 engine saves instead of u)
+    a_out = bf(0.7 * ud / (1 + ud.abs()))
+    ops.gemm(x, w, y0, M, N, K, lda=K, ldb=K, ldc=N, gradmul_pre=a_out, act=5, act_scale=0.7)
+    close_bf16(y0, (x.double() @ w.double().T) * 0.7 * (1 - a_out.double().abs() / 0.7) ** 2, "256-tile softsign' from the output")
+    close_bf16(y0, (x.double() @ w.double().T) * 0.7 / (1 + ud.abs()) ** 2, "256-tile softsign' from the output vs exact", tol=2.5e-2)
 
 
 def _extract_attn_keep_mask(ops, state, site, p, B, heads, Lq, Lk):
