@@ -429,12 +429,15 @@ int align_of(const void* p, int ld) {
 }  // namespace
 
 int mmfm_gemm_big_launch(const mmfm_gemm_desc* dp, hipStream_t st);   // gemm_big.hip: 256 x 256 tiles for the compute-bound shapes
+int mmfm_gemm_dw_launch(const mmfm_gemm_desc* dp, hipStream_t st);    // gemm_dw.hip: the HBM-bound weight-gradient stream
 
 int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     const mmfm_gemm_desc d = *dp;
     {
         const int rb = mmfm_gemm_big_launch(dp, st);
         if (rb != -1000) return rb;
+        const int rw = mmfm_gemm_dw_launch(dp, st);
+        if (rw != -1000) return rw;
     }
     MMFM_REQUIRE(d.splits == 1 || d.kchunk % 64 == 0, "mmfm_gemm(bf16): kchunk %d must be a multiple of 64", d.kchunk);
     static const int bk_env = [] { const char* e = getenv("MMFM_GEMM_BK"); return e ? atoi(e) : 0; }();

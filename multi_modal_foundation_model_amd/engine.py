@@ -372,13 +372,21 @@ class Engine:
         return self._prep
 
     # ------------------------------------------------------------------ plan construction
-    def _dw_split(self, M, N, R):
-        """Split-K factor for a dW GEMM ([M,N] output, reduction over R tokens): tiles x splits fills the persistent
-        grid of the bf16 kernel (256 CUs x 3 workgroups) exactly once - measured against 512 items at B = 1024: qkv dW
-        182 -> 155 us, token-embed dW 639 -> 508 us - capped at 128 slabs (the slab reduction costs S x M x N x 4 bytes)."""
+    def _dw_split(self, M, N, R, ldn=None):
+        """Split-K factor for a dW GEMM ([M,N] output, reduction over R tokens).
+        bf16 shapes the streaming kernel takes (csrc/gemm_dw.hip: 16-B aligned rows of dY [R, M] and X [R, ldn]): ONE (tile, K-slab) item per CU - the slab
+        traffic is items x 64 KB, so fewer, longer items beat filling the chip three times over.
+        Otherwise (fp32 parity path, the 668-wide tokeniser shapes): tiles x splits fills the persistent grid of the 128-tile
+        kernel (256 CUs x 3 workgroups) exactly once - measured against 512 items at B = 1024: qkv dW 182 -> 155 us, token-embed
+        dW 639 -> 508 us - capped at 128 slabs (the slab reduction costs S x M x N x 4 bytes)."""
         tiles = -(-M // 128) * -(-N // 128)
+        stream = self.code == L.BF16 and M % 8 == 0 and (ldn or N) % 8 == 0 and os.environ.get("MMFM_GEMM_DW", "1") != "0"
+        if stream:
+            tiles = L.lib().mmfm_gemm_dw_tiles(M, N)
         if R <= 8192:                     # launch-bound regime (reference batch 16 -> R = 3200): <= 15 slabs = one-stage reduce
             S = max(1, min(R // 256, 15))
+        elif stream:
+            S = max(1, min(R // 512, 256 // tiles))
         else:
             S = max(1, min(R // 512, max(1, 768 // tiles), 128))
         kchunk = _align(-(-R // S), 64)          # multiple of both kernels' BK (32 fp32, 64 bf16)
@@ -405,7 +413,8 @@ class Engine:
 
         # ---- static inputs
         for m, (mod, n) in enumerate(c.mods):
-            buf(f"in/{m}", (BT, n)); buf(f"tgt/{m}", (BT, n), f32); buf(f"mask/{m}", (B, T), i64)
+            # input rows padded to 16 B (zeros): the tokeniser's weight-gradient GEMM streams them by LDS-DMA (csrc/gemm_dw.hip)
+            buf(f"in/{m}", (BT, _align(n, 8)), zero=True); buf(f"tgt/{m}", (BT, n), f32); buf(f"mask/{m}", (B, T), i64)
         ts, attn = buf("ts", (B, T), i64), buf("attn", (B, T), i64)
         tokmask, keypad = buf("tokmask", (B, Lq), u8), buf("keypad", (B, Lq), u8)
         keep0, mod_id, count = buf("keep0", (Lq,), u8), buf("mod_id", (Lq,), u8), buf("count", (M,), i64)
@@ -441,27 +450,29 @@ class Engine:
         ws_st = buf("ws/stitch", (max(1, L.lib().mmfm_stitch_bwd_workspace(code, B, T, Lq, H, c.max_F) // 4),), f32)
         ws_loss = buf("ws/loss", (max(1, L.lib().mmfm_masked_loss_workspace(BT, 1) // 4),), f32)
 
-        def lin(plan, X, wname, Y, Mr, N, Kd, **kw):
-            K.gemm(X, self.W(wname + ".weight"), Y, Mr, N, Kd, lda=Kd, ldb=Kd, ldc=N, bias=self.Pf(wname + ".bias"),
+        def lin(plan, X, wname, Y, Mr, N, Kd, ldx=None, **kw):
+            K.gemm(X, self.W(wname + ".weight"), Y, Mr, N, Kd, lda=ldx or Kd, ldb=Kd, ldc=N, bias=self.Pf(wname + ".bias"),
                    dtype=code, plan=plan, **kw)
 
         used_wt: list = []
 
-        def dlin(plan, dY, X, wname, Mr, N, Kd, dX=None, **kw):
-            """Backward of Y[Mr,N] = X[Mr,Kd] @ W[N,Kd]^T + b:  dW, db into G;  dX = dY @ W (optional, fused epilogue)."""
-            S, kchunk = self._dw_split(N, Kd, Mr)
+        def dlin(plan, dY, X, wname, Mr, N, Kd, dX=None, ldx=None, **kw):
+            """Backward of Y[Mr,N] = X[Mr,Kd] @ W[N,Kd]^T + b:  dW, db into G;  dX = dY @ W (optional, fused epilogue).
+            ldx = row stride of X when its rows are padded."""
+            S, kchunk = self._dw_split(N, Kd, Mr, ldn=ldx)
+            ldx = ldx or Kd
             gw, gb = self.Gv(wname + ".weight"), self.Gv(wname + ".bias")
             # bf16: the bias gradient (column sums of dY) rides on the dW GEMM (mmfm_gemm_desc.colsum); when the bias
             # gradient sits right behind the weight gradient in the flat buffer one slab reduction finishes both
             fused = code == L.BF16
             adjacent = fused and gb.data_ptr() == gw.data_ptr() + 4 * N * Kd
             if S == 1:
-                K.gemm(dY, X, gw, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, dtype=code, c_f32=1,
+                K.gemm(dY, X, gw, N, Kd, Mr, lda=N, ldb=ldx, ldc=Kd, a_kcontig=0, b_kcontig=0, dtype=code, c_f32=1,
                        colsum=gb if fused else None, plan=plan)
             elif adjacent:
                 stride = _align(N * Kd + N)
                 sl = slab_region(S, stride) if batch_red else slab
-                K.gemm(dY, X, sl, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
+                K.gemm(dY, X, sl, N, Kd, Mr, lda=N, ldb=ldx, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
                        slab_stride=stride, dtype=code, c_f32=1, colsum=sl.data_ptr() + 4 * N * Kd, plan=plan)
                 if batch_red:
                     pend.append((gw, sl, N * Kd + N, S, stride, False))
@@ -469,7 +480,7 @@ class Engine:
                     K.reduce_slabs(gw, sl, N * Kd + N, S, stride, plan=plan)
             else:
                 sl = slab_region(S, N * Kd) if batch_red else slab
-                K.gemm(dY, X, sl, N, Kd, Mr, lda=N, ldb=Kd, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
+                K.gemm(dY, X, sl, N, Kd, Mr, lda=N, ldb=ldx, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
                        slab_stride=N * Kd, dtype=code, c_f32=1, plan=plan)
                 if batch_red:
                     pend.append((gw, sl, N * Kd, S, N * Kd, False))
@@ -560,7 +571,7 @@ class Engine:
                 # bf16 mode: the backward takes softsign' from the activation itself (act 5), no saved pre-activation (274 MB per
                 # tokeniser at B = 1024, written here and read back there); the fp32 parity path keeps the exact form
                 z = None if code == L.BF16 else buf(f"{side}/z/{m}", (BT, n2))
-                lin(fwd, self.b[f"in/{m}"], p + ".token_embed", a, BT, n2, n, pre_out=z, act=L.ACT_SOFTSIGN, act_scale=c.embed_scale)
+                lin(fwd, self.b[f"in/{m}"], p + ".token_embed", a, BT, n2, n, ldx=_align(n, 8), pre_out=z, act=L.ACT_SOFTSIGN, act_scale=c.embed_scale)
                 lin(fwd, a, p + ".projection", tok_tmp, BT, H, n2, drop=self._drop(f"{side}/embdrop/{m}", dpe))
                 mod_row = self.Pf(f"encoder_embeddings.{mod}.embedder.mod_emb.weight")[m]
                 K.stitch_fwd(tok_tmp, mod_row, self.Pf(p + ".pos_embed.weight"), ts, keep0, xs, es_, B, T, Lq, m, H, c.max_F, plan=fwd)
@@ -767,7 +778,7 @@ class Engine:
                 else:
                     dlin(cur, self.b[f"d/tok/{side}/{m}"], self.b[f"{side}/a/{m}"], p + ".projection", BT, H, n2, dX=dz,
                          act=L.ACT_SOFTSIGN_GRAD, act_scale=c.embed_scale, gradmul_pre=self.b[f"{side}/z/{m}"])
-                dlin(cur, dz, self.b[f"in/{m}"], p + ".token_embed", BT, n2, n)
+                dlin(cur, dz, self.b[f"in/{m}"], p + ".token_embed", BT, n2, n, ldx=_align(n, 8))
         close_segment("embed")
         if used_wt:                 # refresh the bf16 transposes once per step, in front of everything (the optimiser rewrote the weights)
             tw = self._wt_table()
@@ -800,7 +811,7 @@ class Engine:
     def load_inputs(self, B, T, inputs, targets, masks, ts, attn):
         """Copy one batch into the static input buffers (device tensors or host tensors)."""
         for m in range(len(self.cfg.mods)):
-            self.b[f"in/{m}"].view(B, T, -1).copy_(inputs[m], non_blocking=True)
+            self.b[f"in/{m}"].view(B, T, -1)[..., :inputs[m].shape[-1]].copy_(inputs[m], non_blocking=True)
             self.b[f"tgt/{m}"].view(B, T, -1).copy_(targets[m], non_blocking=True)
             self.b[f"mask/{m}"].copy_(masks[m], non_blocking=True)
         self.b["ts"].copy_(ts, non_blocking=True)

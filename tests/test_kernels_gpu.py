@@ -508,7 +508,10 @@ def test_gemm_bf16_dw_splitk(ops, R, N, K, splits):
 
 
 @pytest.mark.parametrize("R,N,K,splits", [(3200, 256, 256, 8), (1000, 668, 256, 4), (777, 1336, 668, 3), (640, 2, 256, 2), (3200, 768, 256, 1),
-                                          (900, 4, 2, 2), (51200, 512, 256, 40)])
+                                          (900, 4, 2, 2), (51200, 512, 256, 40),
+                                          # the streaming dW kernel (csrc/gemm_dw.hip): ragged tile edges, a reduction that is not a multiple
+                                          # of the k-tile, a short last slab, one item per workgroup at the bench size
+                                          (1000, 200, 72, 3), (1000, 200, 72, 1), (8250, 264, 520, 7), (204800, 768, 256, 42), (204800, 256, 512, 64), (51200, 256, 128, 30)])
 def test_gemm_bf16_dw_with_fused_bias_grad(ops, R, N, K, splits):
     """mmfm_gemm_desc.colsum: the bias gradient (column sums of dY) computed by the dW launch, its partials stored
     behind each weight slab so that one slab reduction yields [dW | db] (the flat gradient buffer's layout)."""
@@ -623,6 +626,26 @@ def test_attention_bf16_dropout_consistency(ops, L, dh):
     ops.attn_bwd(desc)
     dv = dqkv[:, 2 * H:].float().view(B, L, heads, dh)[..., 0]
     close(dv.sum(1), o.float().view(B, L, heads, dh)[..., 0].sum(1), rtol=2e-2, atol=0.5, msg="bf16 fwd/bwd dropout mask agree")
+
+
+def test_gemm_bf16_dw_stream_padded_rows(ops):
+    """The tokeniser's weight gradient (1336 x 668, K = B*T tokens): X rows padded to a 16-B multiple (ld 672) so the streaming kernel takes the
+    shape although N % 8 = 4; the pad columns hold garbage that must not reach the 668 real ones."""
+    R, N, K, ld = 6400, 1336, 668, 672
+    dy = bf(rnd(R, N, seed=18))
+    xp = torch.full((R, ld), float("nan"), device="cuda", dtype=torch.bfloat16)
+    x = bf(rnd(R, K, seed=19))
+    xp[:, :K] = x
+    kchunk = 1600
+    splits = R // kchunk
+    stride = (N * K + N + 7) // 8 * 8
+    slabs = torch.full((splits, stride), float("nan"), device="cuda")
+    out = torch.empty(N * K + N, device="cuda")
+    ops.gemm(dy, xp, slabs, N, K, R, lda=N, ldb=ld, ldc=K, a_kcontig=0, b_kcontig=0, splits=splits, kchunk=kchunk, slab_stride=stride, c_f32=1,
+             colsum=slabs.data_ptr() + 4 * N * K)
+    ops.reduce_slabs(out, slabs, N * K + N, splits, stride)
+    close_bf16(out[:N * K].view(N, K), dy.double().T @ x.double(), "padded-row dW", tol=2e-3)
+    close(out[N * K:], dy.double().sum(0).float(), rtol=1e-5, atol=1e-4 * math.sqrt(R), msg="padded-row bias grad")
 
 
 @pytest.mark.parametrize("M,N,K,Kreal", [(2048 + 100, 512, 512, 512), (1500, 1336, 704, 668), (1100, 256, 1344, 1336), (4096 + 37, 1536, 512, 512),
