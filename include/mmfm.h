@@ -90,9 +90,9 @@ int mmfm_gemm(const mmfm_gemm_desc* d, mmfm_stream stream);
 
 /* dst[i] (+)= sum_s src[s*slab_stride + i], fp32, deterministic order.  `src` is scratch: it may be
  * clobbered (a tall-skinny reduction first sums groups of slabs in place). */
-/* Work items per K-split that a bf16 weight-gradient launch (a_kcontig == b_kcontig == 0, fp32 output, M, N multiples of 8) is cut
- * into: the caller sizes `splits` so that items x splits fills the 256 CUs once (each item writes one M-tile x N-tile fp32 slab). */
-int mmfm_gemm_dw_tiles(int M, int N);
+/* Work items per K-split that a bf16 weight-gradient launch (a_kcontig == b_kcontig == 0, fp32 output, 16-B aligned rows) over K rows is
+ * cut into: the caller sizes `splits` so that items x splits fills the 256 CUs once (each item writes one M-tile x N-tile fp32 slab). */
+int mmfm_gemm_dw_tiles(int M, int N, int K);
 int mmfm_reduce_slabs(float* dst, const float* src, int64_t n, int nslabs, int64_t slab_stride,
                       int accumulate, mmfm_stream stream);
 /* Several slab reductions in ONE launch (small batches: a backward segment's weight-gradient GEMMs each leave a few small

@@ -382,7 +382,7 @@ class Engine:
         tiles = -(-M // 128) * -(-N // 128)
         stream = self.code == L.BF16 and M % 8 == 0 and (ldn or N) % 8 == 0 and os.environ.get("MMFM_GEMM_DW", "1") != "0"
         if stream:
-            tiles = L.lib().mmfm_gemm_dw_tiles(M, N)
+            tiles = L.lib().mmfm_gemm_dw_tiles(M, N, R)
         if R <= 8192:                     # launch-bound regime (reference batch 16 -> R = 3200): <= 15 slabs = one-stage reduce
             S = max(1, min(R // 256, 15))
         elif stream:
@@ -442,7 +442,8 @@ class Engine:
         def slab_region(S, stride):
             o = slabm_off[0]
             slabm_off[0] = o + S * stride
-            assert slabm_off[0] <= slabm.numel(), "ws/slabm too small"
+            if slabm_off[0] > slabm.numel():
+                raise RuntimeError(f"engine: ws/slabm holds {slabm.numel()} floats, the plan's slab regions need {slabm_off[0]}")
             return slabm[o:o + S * stride]
         maxN = max([3 * H, I] + [n * c.mult for _, n in c.mods])
         ws_col = buf("ws/col", (max(1, L.lib().mmfm_colsum_workspace(R, maxN) // 4),), f32)
@@ -526,11 +527,17 @@ class Engine:
                 self.b["ws/lng"] = K.ln_linear_grad_workspace(H, self.device)          # zeroed once; the kernel re-arms its tickets
             ws_lng = self.b["ws/lng"]
 
-        def ln_lin(plan, Xin, lnname, wname, Yout, N, tag, residual=None):
-            """LayerNorm + the linear it feeds in one launch; x_hat / rstd saved for the backward when training."""
+        def ln_lin(plan, Xin, lnname, wname, Yout, N, tag, residual=None, alias=None):
+            """LayerNorm + the linear it feeds in one launch; x_hat / rstd saved for the backward when training.
+            alias = tag of an earlier call on the SAME input: x_hat / rstd do not depend on the LayerNorm's affine (it is folded
+            into the prepared weights), so the earlier call's saved tensors serve this site's backward too and nothing is stored."""
             pw = prep["v"][wname]
-            xh = buf(tag + "/xh", (R, H)) if grad else None
-            rs = buf(tag + "/rs", (R,), f32) if grad else None
+            if alias is not None and grad:
+                self.b[tag + "/xh"], self.b[tag + "/rs"] = self.b[alias + "/xh"], self.b[alias + "/rs"]
+                xh = rs = None
+            else:
+                xh = buf(tag + "/xh", (R, H)) if grad else None
+                rs = buf(tag + "/rs", (R,), f32) if grad else None
             K.rowgemm(Xin, pw["Wp"], Yout, R, N, H, bias=pw["bp"], ln=True, xhat=xh, rstd=rs, residual=residual,
                       ldr=H if residual is not None else 0, stream_out=True, plan=plan)
 
@@ -635,7 +642,8 @@ class Engine:
             qc, kvc, a2, Yb = buf(tag + "/qc", (R, H)), buf(tag + "/kvc", (R, 2 * H)), buf(tag + "/a2", (R, H)), buf(tag + "/yb", (R, H))
             if F_LNL:
                 ln_lin(fwd, Ya, p + ".query_norm", p + ".cross_attn.query", qc, H, tag + "/qn")
-                ln_lin(fwd, context, p + ".context_norm", p + ".cross_attn.kv", kvc, 2 * H, tag + "/cn")
+                # every decoder layer normalises the same context rows: the statistics are saved by the first layer only
+                ln_lin(fwd, context, p + ".context_norm", p + ".cross_attn.kv", kvc, 2 * H, tag + "/cn", alias=None if i == 0 else "dec0/cn")
             else:
                 hq, hc = buf(tag + "/hq", (R, H)), buf(tag + "/hc", (R, H))
                 ln_f(fwd, Ya, p + ".query_norm", hq, tag + "/qn")

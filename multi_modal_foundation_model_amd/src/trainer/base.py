@@ -275,13 +275,28 @@ class MultiModalTrainer():
         """Whole-module pickle like the reference (trainer/base.py:302-308) so its eval scripts can load it; next to it the
         training state the reference never saves (optimiser moments + step, OneCycleLR, dropout / masker / objective RNG) so
         that a run can RESUME: `load_train_state`."""
-        print(f"saving model: {name} to {self.log_dir}")
+        rank, world = self._rank_world()
         model = getattr(self.model, "module", self.model)
-        torch.save({"model": model, "epoch": epoch}, os.path.join(self.log_dir, f"model_{name}.pt"))
+        if rank == 0:                 # replicas are identical: one writer, or concurrent ranks tear the file
+            print(f"saving model: {name} to {self.log_dir}")
+            torch.save({"model": model, "epoch": epoch}, os.path.join(self.log_dir, f"model_{name}.pt"))
         self.save_train_state(name=name, epoch=epoch)
+        if world > 1:
+            torch.distributed.barrier()
 
-    def train_state_path(self, name="last"):
-        return os.path.join(self.log_dir, f"train_state_{name}.pt")
+    @staticmethod
+    def _rank_world():
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+
+    def train_state_path(self, name="last", rank=None):
+        """One file per rank under data parallelism: optimiser state is replicated, but the RNG streams (dropout counter, masker
+        generator, python / numpy objective sampling) are per rank, and a resumed rank needs its own."""
+        rank = self._rank_world()[0] if rank is None else rank
+        world = self._rank_world()[1]
+        return os.path.join(self.log_dir, f"train_state_{name}.pt" if world == 1 else f"train_state_{name}_rank{rank}.pt")
 
     def save_train_state(self, name="last", epoch=0):
         model = getattr(self.model, "module", self.model)
@@ -299,7 +314,8 @@ class MultiModalTrainer():
     def load_train_state(self, path=None, name="last"):
         """Restore what `save_train_state` wrote into THIS trainer (model parameters come from the module pickle or a
         state_dict the caller loaded; the engine is created on the spot so the flat buffers exist).  Returns the epoch."""
-        state = torch.load(path or self.train_state_path(name), weights_only=False)        # our own file
+        # weights_only=False: the file holds python / numpy RNG tuples next to the tensors - only ever a file this trainer wrote
+        state = torch.load(path or self.train_state_path(name), weights_only=False)
         model = getattr(self.model, "module", self.model)
         eng = model.engine()
         self.optimizer.load_state_dict(state["optimizer"])

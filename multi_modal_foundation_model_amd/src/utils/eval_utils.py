@@ -80,12 +80,14 @@ def bits_per_spike_per_neuron(rates, spikes):
 
 # ------------------------------------------------------------------------------------------------ forward-only evaluation driver
 _MASK_MODE = {"per_neuron": "neuron", "forward_pred": "causal", "modal_spike": "causal", "inter_region": "inter-region",
-              "intra_region": "intra-region"}
+              "intra_region": "intra-region", "modal_behavior": "causal"}
 
 
-def eval_mod_dict(model, batch, mask_result, mask_mode, use_mtm=False):
+def eval_mod_dict(model, batch, mask_result, mask_mode, use_mtm=False, masked_mod='ap'):
     """The `mod_dict` the reference's evaluation loops build (utils/eval_utils.py:157-193): unmasked inputs (or the
-    held-out-zeroed spikes with use_mtm), targets = the spikes, eval_mask = the held-out mask; behaviour passes through."""
+    held-out-zeroed spikes with use_mtm), targets = the spikes, eval_mask = the held-out mask; behaviour passes through.
+    masked_mod = 'behavior' is the `modal_behavior` loop (:638-700): the held-out mask sits on the behaviour channels and the
+    spikes pass through with an all-zero eval_mask."""
     dev = batch['spikes_data'].device
     md = {}
     for mod in model.mod_to_indx.keys():
@@ -94,15 +96,15 @@ def eval_mod_dict(model, batch, mask_result, mask_mode, use_mtm=False):
                  targets_timestamp=batch['spikes_timestamps'], eid=batch['eid'][0] if 'eid' in batch else None,
                  num_neuron=batch['spikes_data'].shape[2], masking_mode=model.masker.mode if use_mtm else None)
         if mod == 'ap':
-            d['inputs'] = (mask_result['spikes'] if use_mtm else batch['spikes_data']).clone()
+            d['inputs'] = (mask_result['spikes'] if use_mtm and masked_mod == 'ap' else batch['spikes_data']).clone()
             d['inputs_regions'] = batch.get('neuron_regions')
             d['targets'] = batch['spikes_data'].clone()
-            d['eval_mask'] = mask_result['eval_mask']
+            d['eval_mask'] = mask_result['eval_mask'] if masked_mod == 'ap' else torch.zeros_like(batch['spikes_data']).to(torch.int64)
             d['mask_mode'] = mask_mode
         else:
-            d['inputs'] = batch['target'].clone()
+            d['inputs'] = (mask_result['spikes'] if use_mtm and masked_mod == mod else batch['target']).clone()
             d['targets'] = batch['target'].clone()
-            d['eval_mask'] = torch.zeros_like(batch['target']).to(torch.int64)
+            d['eval_mask'] = mask_result['eval_mask'] if masked_mod == mod else torch.zeros_like(batch['target']).to(torch.int64)
         md[mod] = d
     return md
 
@@ -114,7 +116,9 @@ def co_smoothing_core(model, batch, mode, heldout_idxs=None, target_regions=None
     reference's per-neuron host loop) and the per-trial R^2 of those neurons (mmfm_r2_series).
 
     mode: 'per_neuron' (heldout_idxs = the ONE neuron to hide), 'forward_pred' / 'modal_spike' (heldout_idxs = time bins),
-    'inter_region' / 'intra_region' (target_regions + heldout_idxs within each region; region_list = region of every neuron).
+    'inter_region' / 'intra_region' (target_regions + heldout_idxs within each region; region_list = region of every neuron),
+    'modal_behavior' (heldout_idxs = time bins of the BEHAVIOUR channels, :638-741: scored on the behaviour predictions as they are -
+    no exp, bits/spike undefined = nan like upstream - so "gt" / "rates" are [K, T, n_beh] there and "neurons" the channels).
     Returns {"gt", "rates": [K, T, N] device tensors, "neurons": scored neuron indices, "bins": scored time bins,
     "bps": numpy [len(neurons)] (inf -> nan like upstream), "r2": numpy [len(neurons)] trial-averaged R^2, "loss"}."""
     from multi_modal_foundation_model_amd.metrics import bits_per_spike_per_neuron, r2_series
@@ -131,22 +135,27 @@ def co_smoothing_core(model, batch, mode, heldout_idxs=None, target_regions=None
     elif mode in ('inter_region', 'intra_region'):
         mask_result = heldout_mask(spikes.clone(), mode=mode, heldout_idxs=hd, target_regions=target_regions, neuron_regions=region_list)
         neurons, bins = np.asarray(mask_result['heldout_idxs'], dtype=np.int64), np.arange(T)
+    elif mode == 'modal_behavior':
+        N = batch['target'].shape[2] if n_neurons is None else n_neurons
+        mask_result = heldout_mask(batch['target'].clone(), mode=mode, heldout_idxs=hd, target_regions=None, neuron_regions=region_list)
+        neurons, bins = np.arange(N), hd
     else:
         raise NotImplementedError(f"co_smoothing_core: mode {mode!r}")
+    scored = 'behavior' if mode == 'modal_behavior' else 'ap'
     was_training = model.training
     model.eval()
     try:
         with torch.no_grad():
-            out = model(eval_mod_dict(model, batch, mask_result, _MASK_MODE[mode], use_mtm=use_mtm))
+            out = model(eval_mod_dict(model, batch, mask_result, _MASK_MODE[mode], use_mtm=use_mtm, masked_mod=scored))
     finally:
         model.train(was_training)
-    gt = out.mod_targets['ap'][:, :, :N]
-    rates = torch.exp(out.mod_preds['ap'][:, :, :N])
+    gt = out.mod_targets[scored][:, :, :N]
+    rates = out.mod_preds[scored][:, :, :N] if scored == 'behavior' else torch.exp(out.mod_preds['ap'][:, :, :N])
     n_idx = torch.as_tensor(neurons, device=gt.device)
     t_idx = torch.as_tensor(bins, device=gt.device)
     g_sel = gt.index_select(1, t_idx).index_select(2, n_idx).contiguous()
     r_sel = rates.index_select(1, t_idx).index_select(2, n_idx).contiguous()
-    bps = bits_per_spike_per_neuron(r_sel, g_sel).cpu().numpy()
+    bps = np.full(len(neurons), np.nan) if scored == 'behavior' else bits_per_spike_per_neuron(r_sel, g_sel).cpu().numpy()
     r2 = r2_series(g_sel, r_sel).double().cpu().numpy()                     # [K, n]: R^2 over the scored bins, per trial and neuron
     r2 = np.asarray([np.ma.masked_invalid(r2[:, j]).mean() for j in range(r2.shape[1])], dtype=np.float64)
     return dict(gt=gt, rates=rates, neurons=neurons, bins=bins, bps=bps, r2=r2, loss=out.loss)

@@ -837,7 +837,71 @@ EVAL_DRIVER_CASES = [
     dict(mode="inter_region", target_regions=["CA1", "PO"], heldout_idxs=[0, 1]),
     dict(mode="intra_region", target_regions=["CA1"], heldout_idxs=[1]),
     dict(mode="modal_spike", held_out_list=[0, 1, 2, 3, 4, 5, 6, 7]),
+    dict(mode="modal_behavior", held_out_list=[2, 3, 4, 5]),
 ]
+
+
+def _eval_runner(model, batch, regions, K_, N):
+    """mod_dict of the reference's evaluation loops (utils/eval_utils.py:157-193; :660-692 for modal_behavior, where the held-out mask sits on
+    the behaviour channels) -> eval forward -> (targets, exp(preds) or the raw behaviour predictions, loss)."""
+    def run(mask_result, mask_mode, masked="ap"):
+        md = {}
+        for mod in model.mod_to_indx.keys():
+            md[mod] = dict(inputs_modality=torch.tensor(model.mod_to_indx[mod]), targets_modality=torch.tensor(model.mod_to_indx[mod]),
+                           inputs_attn_mask=batch["time_attn_mask"], inputs_timestamp=batch["spikes_timestamps"],
+                           targets_timestamp=batch["spikes_timestamps"], eid="synthetic", num_neuron=N, masking_mode=None)
+            if mod == "ap":
+                md[mod].update(inputs=batch["spikes_data"].clone(), inputs_regions=np.asarray([regions] * K_),
+                               targets=batch["spikes_data"].clone(), mask_mode=mask_mode,
+                               eval_mask=mask_result["eval_mask"] if masked == "ap" else torch.zeros_like(batch["spikes_data"]).to(torch.int64))
+            else:
+                md[mod].update(inputs=batch["target"].clone(), targets=batch["target"].clone(),
+                               eval_mask=mask_result["eval_mask"] if masked == mod else torch.zeros_like(batch["target"]).to(torch.int64))
+        with torch.no_grad():
+            out = model(md)
+        if masked == "ap":
+            return out.mod_targets["ap"][:, :, :N].numpy(), torch.exp(out.mod_preds["ap"][:, :, :N]).numpy(), float(out.loss)
+        nb = batch["target"].shape[2]
+        return out.mod_targets[masked][:, :, :nb].numpy(), out.mod_preds[masked][:, :, :nb].numpy(), float(out.loss)
+    return run
+
+
+def _eval_cases(cases_in, run, spikes, beh, regions, heldout_mask, bps_list, arrs, keep_rates):
+    """Runs every evaluation case through the reference's pieces; keep_rates(cid, tag, rates) stores what the fixture keeps of the rates."""
+    cases = []
+    for cid, c in enumerate(cases_in):
+        out = dict(c)
+        if c["mode"] == "per_neuron":
+            bl = []
+            for j, n_i in enumerate(c["neurons"]):
+                mr = heldout_mask(spikes.clone(), mode="manual", heldout_idxs=np.array([n_i]))
+                gt, pr, loss = run(mr, "neuron")
+                keep_rates(cid, f"rates{j}", pr)
+                bl.append(bps_list(gt[:, :, [n_i]], pr[:, :, [n_i]])[0])
+            out["bps"] = bl
+        elif c["mode"] in ("forward_pred", "modal_spike"):
+            mr = heldout_mask(spikes.clone(), mode=c["mode"], heldout_idxs=np.array(c["held_out_list"]), target_regions=None, neuron_regions=regions)
+            gt, pr, loss = run(mr, "causal")
+            keep_rates(cid, "rates", pr)
+            t_i = c["held_out_list"]
+            out["bps"] = bps_list(gt[:, t_i], pr[:, t_i])
+        elif c["mode"] == "modal_behavior":
+            mr = heldout_mask(beh.clone(), mode="modal_behavior", heldout_idxs=np.array(c["held_out_list"]), target_regions=None, neuron_regions=regions)
+            gt, pr, loss = run(mr, "causal", masked="behavior")
+            keep_rates(cid, "rates", pr)
+            out["bps"] = [float("nan")] * gt.shape[2]               # utils/eval_utils.py:709-710
+        else:
+            mr = heldout_mask(spikes.clone(), mode=c["mode"], heldout_idxs=np.array(c["heldout_idxs"]), target_regions=c["target_regions"],
+                              neuron_regions=regions)
+            gt, pr, loss = run(mr, "inter-region" if c["mode"] == "inter_region" else "intra-region")
+            keep_rates(cid, "rates", pr)
+            n_i = np.asarray(mr["heldout_idxs"])
+            out["heldout"] = n_i.tolist()
+            out["bps"] = bps_list(gt[:, :, n_i], pr[:, :, n_i])
+        out["loss"] = loss
+        cases.append(out)
+        print("   ", c["mode"], [round(b, 4) for b in out["bps"][:4]], loss)
+    return cases
 
 
 def fx_eval_driver():
@@ -865,21 +929,7 @@ def fx_eval_driver():
     arrs.update(spikes=npify(spikes), behavior=npify(beh))
     arrs["regions"] = np.frombuffer(json.dumps(regions.tolist()).encode(), dtype=np.uint8)
 
-    def run(mask_result, mask_mode):
-        md = {}
-        for mod in model.mod_to_indx.keys():
-            md[mod] = dict(inputs_modality=torch.tensor(model.mod_to_indx[mod]), targets_modality=torch.tensor(model.mod_to_indx[mod]),
-                           inputs_attn_mask=batch["time_attn_mask"], inputs_timestamp=batch["spikes_timestamps"],
-                           targets_timestamp=batch["spikes_timestamps"], eid="synthetic", num_neuron=N, masking_mode=None)
-            if mod == "ap":
-                md[mod].update(inputs=batch["spikes_data"].clone(), inputs_regions=np.asarray([regions] * K_),
-                               targets=batch["spikes_data"].clone(), eval_mask=mask_result["eval_mask"], mask_mode=mask_mode)
-            else:
-                md[mod].update(inputs=batch["target"].clone(), targets=batch["target"].clone(),
-                               eval_mask=torch.zeros_like(batch["target"]).to(torch.int64))
-        with torch.no_grad():
-            out = model(md)
-        return out.mod_targets["ap"][:, :, :N].numpy(), torch.exp(out.mod_preds["ap"][:, :, :N]).numpy(), float(out.loss)
+    run = _eval_runner(model, batch, regions, K_, N)
 
     def bps_list(gt, pr):
         res = []
@@ -889,44 +939,73 @@ def fx_eval_driver():
             res.append(float("nan") if np.isinf(b) else float(b))
         return res
 
-    cases = []
-    for cid, c in enumerate(EVAL_DRIVER_CASES):
-        out = dict(c)
-        if c["mode"] == "per_neuron":
-            bl = []
-            for j, n_i in enumerate(c["neurons"]):
-                mr = heldout_mask(spikes.clone(), mode="manual", heldout_idxs=np.array([n_i]))
-                gt, pr, loss = run(mr, "neuron")
-                arrs[f"c{cid}/rates{j}"] = pr.astype(np.float32)
-                bl.append(bps_list(gt[:, :, [n_i]], pr[:, :, [n_i]])[0])
-            out["bps"] = bl
-        elif c["mode"] in ("forward_pred", "modal_spike"):
-            mr = heldout_mask(spikes.clone(), mode=c["mode"], heldout_idxs=np.array(c["held_out_list"]), target_regions=None, neuron_regions=regions)
-            gt, pr, loss = run(mr, "causal")
-            arrs[f"c{cid}/rates"] = pr.astype(np.float32)
-            t_i = c["held_out_list"]
-            out["bps"] = bps_list(gt[:, t_i], pr[:, t_i])
-        elif c["mode"] == "inter_region":
-            mr = heldout_mask(spikes.clone(), mode="inter_region", heldout_idxs=np.array(c["heldout_idxs"]), target_regions=c["target_regions"],
-                              neuron_regions=regions)
-            gt, pr, loss = run(mr, "inter-region")
-            arrs[f"c{cid}/rates"] = pr.astype(np.float32)
-            n_i = np.asarray(mr["heldout_idxs"])
-            out["heldout"] = n_i.tolist()
-            out["bps"] = bps_list(gt[:, :, n_i], pr[:, :, n_i])
-        else:
-            mr = heldout_mask(spikes.clone(), mode="intra_region", heldout_idxs=np.array(c["heldout_idxs"]), target_regions=c["target_regions"],
-                              neuron_regions=regions)
-            gt, pr, loss = run(mr, "intra-region")
-            arrs[f"c{cid}/rates"] = pr.astype(np.float32)
-            n_i = np.asarray(mr["heldout_idxs"])
-            out["heldout"] = n_i.tolist()
-            out["bps"] = bps_list(gt[:, :, n_i], pr[:, :, n_i])
-        out["loss"] = loss
-        cases.append(out)
-        print("   ", c["mode"], out["bps"][:4], loss)
+    def keep(cid, tag, pr):
+        arrs[f"c{cid}/{tag}"] = pr.astype(np.float32)
+    cases = _eval_cases(EVAL_DRIVER_CASES, run, spikes, beh, regions, heldout_mask, bps_list, arrs, keep)
     arrs["meta"] = np.frombuffer(json.dumps(dict(cases=cases, K=K_, T=T, N=N, model_seed=21)).encode(), dtype=np.uint8)
     save_npz("eval_driver.npz", **arrs)
+
+
+EVAL_BIG_CASES = [
+    dict(mode="per_neuron", neurons=[3, 400]),
+    dict(mode="forward_pred", held_out_list=list(range(90, 100))),
+    dict(mode="inter_region", target_regions=["CA1", "PO"], heldout_idxs=[0, 5, 17]),
+    dict(mode="intra_region", target_regions=["LP"], heldout_idxs=[2, 3]),
+    dict(mode="modal_spike", held_out_list=list(range(100))),
+    dict(mode="modal_behavior", held_out_list=list(range(40, 60))),
+]
+EVAL_BIG = dict(K=64, T=100, N=668, model_seed=5, data_seed=177, rate_stride=(8, 10, 16))
+
+
+def eval_big_inputs():
+    """Synthetic test set of the big evaluation fixture, regenerated from seeds on both sides (17 MB of spikes are not committed)."""
+    K_, T, N = EVAL_BIG["K"], EVAL_BIG["T"], EVAL_BIG["N"]
+    g = torch.Generator().manual_seed(EVAL_BIG["data_seed"])
+    base = 0.2 + 1.6 * torch.rand(N, generator=g)
+    spikes = torch.poisson(base.expand(K_, T, N).contiguous(), generator=g)
+    beh = torch.randn(K_, T, 2, generator=g)
+    names = np.array(["CA1", "PO", "LP", "DG", "VISa"])
+    regions = names[torch.randint(0, 5, (N,), generator=g).numpy()]
+    return spikes, beh, regions
+
+
+def fx_eval_driver_big():
+    """fx_eval_driver at the size the evaluation runs at: a test set of K = 64 trials, T = 100 bins, N = 668 neurons through
+    the DEFAULT model (d_model 256, 5 + 5 layers, built from a seed on both sides), every mode incl. modal_behavior.  Kept: the per-neuron
+    bits/spike of every case, the loss, and a strided sample of the rates."""
+    import datasets
+    if not hasattr(datasets, "list_datasets"):
+        datasets.list_datasets = lambda *a, **k: []
+    _stub_wandb_torcheval()
+    import matplotlib
+    matplotlib.use("Agg")
+    from utils.eval_utils import bits_per_spike, heldout_mask
+    K_, T, N = EVAL_BIG["K"], EVAL_BIG["T"], EVAL_BIG["N"]
+    model = build_model(ref_config().model, N, 2, seed=EVAL_BIG["model_seed"])
+    model.eval()
+    spikes, beh, regions = eval_big_inputs()
+    batch = dict(spikes_data=spikes, target=beh, time_attn_mask=torch.ones(K_, T, dtype=torch.int64),
+                 spikes_timestamps=torch.arange(T).unsqueeze(0).repeat(K_, 1))
+    run = _eval_runner(model, batch, regions, K_, N)
+
+    def bps_list(gt, pr):
+        res = []
+        for n_i in range(gt.shape[2]):
+            with np.errstate(divide="ignore", invalid="ignore"):
+                b = bits_per_spike(pr[:, :, [n_i]].astype(np.float64), gt[:, :, [n_i]].astype(np.float64))
+            res.append(float("nan") if np.isinf(b) else float(b))
+        return res
+
+    arrs = {}
+    sk, st_, sn = EVAL_BIG["rate_stride"]
+
+    def keep(cid, tag, pr):
+        arrs[f"c{cid}/{tag}"] = pr[::sk, ::st_, ::sn].astype(np.float32)
+        arrs[f"c{cid}/{tag}_sum"] = np.asarray(pr.astype(np.float64).sum(axis=(0, 1)))
+    cases = _eval_cases(EVAL_BIG_CASES, run, spikes, beh, regions, heldout_mask, bps_list, arrs, keep)
+    arrs["spikes_sum"] = np.asarray(spikes.double().sum(dim=(0, 1)).numpy())          # guards the regenerated inputs
+    arrs["meta"] = np.frombuffer(json.dumps(dict(cases=cases, **EVAL_BIG)).encode(), dtype=np.uint8)
+    save_npz("eval_driver_big.npz", **arrs)
 
 
 def main():
@@ -935,7 +1014,7 @@ def main():
     for name, fn in [("init_order", fx_init_order), ("tiny_fwd_bwd", fx_tiny_fwd_bwd),
                      ("default_scalars", fx_default_scalars), ("masker_bits", fx_masker_bits),
                      ("mask_index_ops", fx_mask_index_ops), ("sched_adamw", fx_sched_adamw),
-                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("multisession_curve", fx_multisession_curve), ("eval_metrics", fx_eval_metrics), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate), ("masker_modes", fx_masker_modes), ("masker_modes_model", fx_masker_modes_model), ("eval_driver", fx_eval_driver),
+                     ("loss_curve", fx_loss_curve), ("loss_curve_1k", fx_loss_curve_1k), ("config5_scalars", fx_config5_scalars), ("multisession_curve", fx_multisession_curve), ("eval_metrics", fx_eval_metrics), ("trainer_io", fx_trainer_io), ("loader_collate", fx_loader_collate), ("masker_modes", fx_masker_modes), ("masker_modes_model", fx_masker_modes_model), ("eval_driver", fx_eval_driver), ("eval_driver_big", fx_eval_driver_big),
                      ("h64_curve", fx_h64_curve), ("multisession_big", fx_multisession_big), ("loss_curve_1k_default", fx_loss_curve_1k_default)]:
         if only and name not in only:
             continue

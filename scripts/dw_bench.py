@@ -24,7 +24,7 @@ for name, R, N, K in [("qkv 768x256", 204800, 768, 256), ("up 512x256", 204800, 
     tiles = -(-N // 128) * -(-K // 128)
     if new:
         from multi_modal_foundation_model_amd import _lib as L
-        tiles = L.lib().mmfm_gemm_dw_tiles(N, K)
+        tiles = L.lib().mmfm_gemm_dw_tiles(N, K, 204800)
     S = over or (max(1, min(256 // tiles, R // 512)) if new else max(1, min(R // 512, max(1, 768 // tiles), 128)))
     kchunk = (-(-R // S) + 63) // 64 * 64
     S = -(-R // kchunk)

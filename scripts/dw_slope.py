@@ -14,7 +14,7 @@ def t(fn):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 for name, N, K in [("qkv 768x256", 768, 256), ("proj 256x256", 256, 256), ("down 256x512", 256, 512)]:
-    tiles = L.lib().mmfm_gemm_dw_tiles(N, K)
+    tiles = L.lib().mmfm_gemm_dw_tiles(N, K, 204800)
     S0 = 256 // tiles
     pts = []
     for R in (51200, 102400, 204800, 409600):

@@ -2,7 +2,6 @@
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["MMFM_LIB"] = os.path.join(ROOT, "multi_modal_foundation_model_amd", "libmmfm_stamp.so")
-os.environ["MMFM_MLP_BWD_V1"] = "1"
 sys.path.insert(0, ROOT)
 import torch
 from multi_modal_foundation_model_amd import ops, _lib as L

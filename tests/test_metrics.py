@@ -144,4 +144,50 @@ def test_eval_driver_vs_reference_core_fixture():
         if not np.isnan(c["loss"]):
             assert res["loss"].item() == pytest.approx(c["loss"], rel=1e-4)
         assert res["r2"].shape == (len(res["neurons"]),)
+    assert {c["mode"] for c in meta["cases"]} == {"per_neuron", "forward_pred", "inter_region", "intra_region", "modal_spike", "modal_behavior"}
     assert model.training
+
+
+@pytest.mark.gpu
+def test_eval_driver_at_evaluation_size_vs_reference_fixture():
+    """The same driver at the size an evaluation runs at: K = 64 test trials, T = 100, N = 668 through the default model (d_model 256, 5 + 5
+    layers; model and inputs regenerated from the fixture's seeds), every mode incl. modal_behavior.  Pinned: per-neuron bits/spike of
+    all 668 neurons, the loss, per-neuron rate sums and a strided sample of the rates (tests/golden/eval_driver_big.npz, made by
+    importing the reference: oracle/make_goldens.py:fx_eval_driver_big)."""
+    from helpers import build_model, model_config
+    from utils.eval_utils import co_smoothing_core
+    z, meta = load_npz("eval_driver_big.npz")
+    K_, T, N = meta["K"], meta["T"], meta["N"]
+    g = torch.Generator().manual_seed(meta["data_seed"])              # = oracle/make_goldens.py:eval_big_inputs
+    base = 0.2 + 1.6 * torch.rand(N, generator=g)
+    spikes = torch.poisson(base.expand(K_, T, N).contiguous(), generator=g)
+    beh = torch.randn(K_, T, 2, generator=g)
+    regions = np.array(["CA1", "PO", "LP", "DG", "VISa"])[torch.randint(0, 5, (N,), generator=g).numpy()]
+    np.testing.assert_array_equal(spikes.double().sum(dim=(0, 1)).numpy(), z["spikes_sum"])
+    model = build_model(model_config(), N, 2, seed=meta["model_seed"]).cuda().train()
+    batch = dict(spikes_data=spikes.cuda(), target=beh.cuda(), time_attn_mask=torch.ones(K_, T, dtype=torch.int64, device="cuda"),
+                 spikes_timestamps=torch.arange(T, device="cuda").unsqueeze(0).repeat(K_, 1), eid=["synthetic"] * K_,
+                 neuron_regions=np.asarray([regions] * K_))
+    sk, st_, sn = meta["rate_stride"]
+
+    def check(res, cid, tag, c):
+        r = res["rates"].cpu().numpy()
+        np.testing.assert_allclose(r[::sk, ::st_, ::sn], z[f"c{cid}/{tag}"], rtol=5e-4, atol=1e-5, err_msg=c["mode"])
+        np.testing.assert_allclose(r.astype(np.float64).sum(axis=(0, 1)), z[f"c{cid}/{tag}_sum"], rtol=1e-4, err_msg=c["mode"])
+    for cid, c in enumerate(meta["cases"]):
+        if c["mode"] == "per_neuron":
+            for j, n_i in enumerate(c["neurons"]):
+                res = co_smoothing_core(model, batch, "per_neuron", heldout_idxs=[n_i], region_list=regions)
+                check(res, cid, f"rates{j}", c)
+                assert res["bps"][0] == pytest.approx(c["bps"][j], rel=2e-3, abs=2e-4)
+            continue
+        hd = c.get("held_out_list", c.get("heldout_idxs"))
+        res = co_smoothing_core(model, batch, c["mode"], heldout_idxs=hd, target_regions=c.get("target_regions"), region_list=regions)
+        check(res, cid, "rates", c)
+        if "heldout" in c:
+            assert list(res["neurons"]) == c["heldout"]
+        assert len(res["bps"]) == len(c["bps"])
+        np.testing.assert_allclose(res["bps"], np.asarray(c["bps"], dtype=np.float64), rtol=2e-3, atol=5e-4, equal_nan=True, err_msg=c["mode"])
+        if not np.isnan(c["loss"]):
+            assert res["loss"].item() == pytest.approx(c["loss"], rel=1e-4)
+        assert res["r2"].shape == (len(res["neurons"]),)
