@@ -260,8 +260,8 @@ int mmfm_bits_per_spike_neurons(const float* rates, const float* spikes, int64_t
  *
  * mmfm_prep_weights: per training step (weights change) the LayerNorm affine is folded into the linear it feeds,
  *   Wp[n][k] = bf16(W[n][k] * gamma[k]),  WpT = Wp^T,  bp[n] = bias[n] + sum_k W[n][k] * beta[k]
- * so that  linear(layernorm(x)) = Wp . x_hat + bp  with  x_hat = (x - mean) * rstd.  gamma / beta / bias / Wp / WpT / bp may be
- * NULL (plain bf16 copies / transposes of a weight).  `entries` is a DEVICE array; entry e covers blocks
+ * so that  linear(layernorm(x)) = Wp . x_hat + bp  with  x_hat = (x - mean) * rstd.  gamma / beta / bias / Wp / WpT / bp / WpP / WpTP
+ * may be NULL (plain bf16 copies / transposes of a weight).  `entries` is a DEVICE array; entry e covers blocks
  * [tile0, tile0 + ceil(N/32)); total_tiles = sum of ceil(N/32). */
 typedef struct {
     const float* W;          /* [N][K] fp32 master weight */
@@ -274,6 +274,11 @@ typedef struct {
     int N, K;
     int tile0;
     int pad_;
+    void* WpP;               /* bf16 [N][K] or NULL: Wp with the 8-byte units of every aligned 32-byte group of a row in the order
+                                0, 2, 1, 3 ("unit-permuted": the order in which an MFMA accumulator tile, used as the next product's
+                                operand, holds its k index - rowchain.h).  LDS-DMA cannot permute on the way in, so the kernels that
+                                multiply such operands read these copies: mmfm_mlp_fwd's w_down */
+    void* WpTP;              /* bf16 [K][N] or NULL: WpT unit-permuted along N: mmfm_mlp_bwd's w_up_t */
 } mmfm_prep_entry;
 int mmfm_prep_weights(const mmfm_prep_entry* entries, int n_entries, int total_tiles, mmfm_stream stream);
 

@@ -54,7 +54,8 @@ class AttnDesc(C.Structure):
 
 class PrepEntry(C.Structure):
     _fields_ = [("W", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("bias", C.c_void_p), ("Wp", C.c_void_p),
-                ("WpT", C.c_void_p), ("bp", C.c_void_p), ("N", C.c_int), ("K", C.c_int), ("tile0", C.c_int), ("pad_", C.c_int)]
+                ("WpT", C.c_void_p), ("bp", C.c_void_p), ("N", C.c_int), ("K", C.c_int), ("tile0", C.c_int), ("pad_", C.c_int),
+                ("WpP", C.c_void_p), ("WpTP", C.c_void_p)]
 
 
 class ReduceEntry(C.Structure):

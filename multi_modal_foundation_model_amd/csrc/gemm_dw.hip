@@ -39,9 +39,14 @@ constexpr int TM = 128, DNT = 256;
 constexpr uint32_t OOB = 0x80000000u;     // beyond every descriptor's num_records (< 2^31, checked on the host): the load returns zeros
 
 // TN = output-tile width (the A panel is 128 wide), BK = k-tile depth; the ring takes what fits in 160 KB
+// (MMFM_DW_LDS_KB: diagnostic builds with a smaller ring, scripts/probe/build_dw_lds.sh)
+#ifndef MMFM_DW_LDS_KB
+#define MMFM_DW_LDS_KB 160
+#endif
 template <int TN, int BK> struct Geo {
     static constexpr int OPA = BK * TM * 2, OPB = BK * TN * 2, STB = OPA + OPB;
-    static constexpr int NST = (160 * 1024) / STB < 8 ? (160 * 1024) / STB : 8;
+    static constexpr int NST = (MMFM_DW_LDS_KB * 1024) / STB < 8 ? (MMFM_DW_LDS_KB * 1024) / STB : 8;
+    static_assert(NST >= 3, "ring needs three stages");
     static constexpr int LDS = NST * STB;
     static constexpr int NA = BK / 16;            // DMA instructions per wave and k-tile, A (1 KB = 4 rows x 256 B each)
     static constexpr int NB = NA * (TN / TM);     // ... and B (1 KB = 512 / TN-bytes rows)
@@ -260,7 +265,6 @@ extern "C" int mmfm_gemm_dw_tiles(int M, int N, int K) { return cdiv(M, TM) * cd
 int mmfm_gemm_dw_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     const mmfm_gemm_desc& d = *dp;
     static const int on = [] { const char* e = getenv("MMFM_GEMM_DW"); return e ? atoi(e) : 1; }();
-    static const int bk_env = [] { const char* e = getenv("MMFM_GEMM_DW_BK"); return e ? atoi(e) : 32; }();
     const bool f32out = d.c_f32 || d.splits > 1;
     if (!on || d.dtype != MMFM_BF16 || !f32out || d.a_kcontig || d.b_kcontig) return -1000;
     if (d.bias || d.pre_out || d.gradmul_pre || d.residual || d.act || (d.drop.p > 0.f)) return -1000;
@@ -270,6 +274,5 @@ int mmfm_gemm_dw_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     if (d.splits > 1 && (d.kchunk % 64 || d.kchunk <= 0)) return -1000;
     if (((int64_t)d.K + 9 * 64) * std::max(d.lda, d.ldb) * 2 >= (int64_t)1 << 31) return -1000;          // 32-bit buffer offsets, ring run-out included
     const bool wide = dw_wide(d.N, d.K);
-    if (wide) return bk_env == 64 ? launch<256, 64>(d, st) : launch<256, 32>(d, st);
-    return bk_env == 64 ? launch<128, 64>(d, st) : launch<128, 32>(d, st);
+    return wide ? launch<256, 32>(d, st) : launch<128, 32>(d, st);
 }

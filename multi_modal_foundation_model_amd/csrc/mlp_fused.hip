@@ -26,8 +26,8 @@ __device__ unsigned long long mmfm_probe_acc[16];
 #define STAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_a[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define STAMP(i) do { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_a[i] += n_ - st_t; st_t = n_; } while (0)
 #define STAMP_FLUSH do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&mmfm_probe_acc[i_], st_a[i_]); } while (0)
-extern "C" int mmfm_probe_read(unsigned long long* host8, int reset) {
-    (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(mmfm_probe_acc), 64);
+extern "C" int mmfm_probe_read(unsigned long long* host16, int reset) {
+    (void)hipMemcpyFromSymbol(host16, HIP_SYMBOL(mmfm_probe_acc), 128);
     if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(mmfm_probe_acc), z, 128); }
     return 0;
 }
@@ -46,37 +46,46 @@ constexpr int NT = 256, NW = 4;
 #define MMFM_PROBE 0
 #endif
 __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
-    // + a 16 KB per-wave stash of the pass's x_hat rows (four [32 rows][128 B] staging images): the LayerNorm-backward epilogue reads
-    // x_hat twice more, and fetching it from memory again put two more dependent round trips (and 210 MB) into every pass
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + 3 * NW * STG_BYTES + 512 * 4 + NW * 4 * STG_BYTES];
+    // LDS: three 16 KB ring slots (asynchronous ring, rowchain.h) | per-wave staging for g and du (the g area doubles as the
+    // prologue / epilogue staging) | b_up | a 16 KB per-wave stash of the pass's x_hat rows (four [32 rows][128 B] staging images):
+    // the LayerNorm-backward epilogue reads x_hat twice more, and fetching it from memory again put two more dependent round trips
+    // (and 210 MB) into every pass
+    constexpr int RING_B = RINGA_SLOTS * CHUNK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // RING_B + 2 * NW * STG_BYTES + 512 * 4 + NW * 4 * STG_BYTES
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
     const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
     const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
     if (my_passes == 0) return;
-    char* xstash = smem + LDS_BYTES + 3 * NW * STG_BYTES + 512 * 4 + wave * 4 * STG_BYTES;
-    const uint16_t* Wup = reinterpret_cast<const uint16_t*>(d.w_up);
-    const uint16_t* WdnT = reinterpret_cast<const uint16_t*>(d.w_down_t);
-    const uint16_t* WupT = reinterpret_cast<const uint16_t*>(d.w_up_t);
+    char* xstash = smem + RING_B + 2 * NW * STG_BYTES + 512 * 4 + wave * 4 * STG_BYTES;
+    const __amdgpu_buffer_rsrc_t rs_up = wbuf(d.w_up), rs_dnt = wbuf(d.w_down_t), rs_upt = wbuf(d.w_up_t);
     const int rot = d.rotate ? (int)(blockIdx.x & 7) * 2 : 0;            // even: tile pairs of g / du complete together
+    // chunk sequence of a tile ti: Wp_up rows (recompute u), W_down^T rows (dg), Wp_up^T columns (d x_hat; unit-permuted copy)
     auto src = [=](int g) {
-        const int idx = g % 48, ti = idx / 3, k = idx - 3 * ti, tt = (ti + rot) & 15;
-        WChunk c;
-        if (k == 0) { c.base = Wup + (size_t)(32 * tt) * 256; c.ld = 256; c.kind = 0; }
-        else if (k == 1) { c.base = WdnT + (size_t)(32 * tt) * 256; c.ld = 256; c.kind = 0; }
-        else { c.base = WupT + 32 * tt; c.ld = 512; c.kind = 2; }
+        const int idx = g % 48;                             // up(0) dg(0) | up(ti) dg(ti) dh(ti-1), ti = 1..15 | dh(15)
+        int ti, k;
+        if (idx < 2) { ti = 0; k = idx; }
+        else if (idx == 47) { ti = 15; k = 2; }
+        else { const int j = idx - 2; ti = j / 3 + 1; k = j - 3 * (ti - 1); if (k == 2) --ti; }
+        const int tt = (ti + rot) & 15;
+        AChunk c;
+        if (k == 0) { c.rs = rs_up; c.off = (uint32_t)(32 * tt) * 512u; c.ldb = 512u; c.kind = 0; }
+        else if (k == 1) { c.rs = rs_dnt; c.off = (uint32_t)(32 * tt) * 512u; c.ldb = 512u; c.kind = 0; }
+        else { c.rs = rs_upt; c.off = (uint32_t)(32 * tt) * 2u; c.ldb = 1024u; c.kind = 2; }
         return c;
     };
-    char* stg = smem + LDS_BYTES + wave * STG_BYTES;
-    char* stg_g = smem + LDS_BYTES + (NW + wave) * STG_BYTES;
-    char* stg_du = smem + LDS_BYTES + (2 * NW + wave) * STG_BYTES;
-    float* lb_up = reinterpret_cast<float*>(smem + LDS_BYTES + 3 * NW * STG_BYTES);
+    char* stg_g = smem + RING_B + wave * STG_BYTES;
+    char* stg_du = smem + RING_B + (NW + wave) * STG_BYTES;
+    char* stg = stg_g;                                                   // prologue / epilogue staging: the loop's g area is idle then
+    float* lb_up = reinterpret_cast<float*>(smem + RING_B + 2 * NW * STG_BYTES);
     stage_vec(lb_up, d.b_up, 512, t, NT);
     const Drop dr = drop_init(d.drop);
     const GBuf XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4), DY = gbuf(d.dy, d.R * d.lddy * 2), T1 = gbuf(d.t1, d.R * 512);
     const GBuf G = gbuf(d.g, d.R * 1024), DU = gbuf(d.du, d.R * 1024), DX = gbuf(d.dx, d.R * d.lddx * 2);
     const uint32_t lddyb = d.lddy * 2, lddxb = d.lddx * 2;
-    RING_DECL(NT);
-    RING_START(smem, my_passes * 48, src);
+    const ALane<NT> ring_al = alane_init<NT>(t, 512u, 1024u);
+    const AFrag fr = afrag_init(m, h);
+    RINGA_DECL(NT);
+    RINGA_START((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem, my_passes * 48, src);
     STAMP_DECL;
     for (int pi = 0; pi < my_passes; ++pi) {
         const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
@@ -108,40 +117,76 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) DH[i] = zero16();
         STAMP(0);
-        for (int ti = 0; ti < 16; ++ti) {
-            const int tt = (ti + rot) & 15;
-            const char* slot;
-            RING_STEP(src, slot);
+        // Software pipeline over the 16 intermediate tiles: the d(x_hat) MFMAs of tile ti-1 are issued BETWEEN the GELU pairs of tile ti
+        // (hipcc would cluster them in front of the vector work: one wave per SIMD, nothing else to fill the MFMA pipe's shadow), so
+        // the ring carries  up(0) dg(0) | up(1) dg(1) dh(0) | ... | up(15) dg(15) dh(14) | dh(15).
+        // ODD tiles complete a pair of g / du tiles: their 16 line stores leave at the end of the iteration, and the next two ring
+        // steps may therefore leave eight more operations in flight (RINGA_STEP_X).
+        opnd d0, d1;                                         // du operands of the previous tile
+#define DH_READS(SET, Q) do { ALDS_READ_B(wv[SET][0], slot, fr, 2 * (Q), 0); ALDS_READ_B(wv[SET][1], slot, fr, 2 * (Q), 1);          \
+                              ALDS_READ_B(wv[SET][2], slot, fr, 2 * (Q) + 1, 0); ALDS_READ_B(wv[SET][3], slot, fr, 2 * (Q) + 1, 1); } while (0)
+#define DH_MMAS(SET, Q) do { DH[2 * (Q)] = mfma_u4(wv[SET][0], d0, DH[2 * (Q)]); DH[2 * (Q) + 1] = mfma_u4(wv[SET][2], d0, DH[2 * (Q) + 1]);  \
+                             DH[2 * (Q)] = mfma_u4(wv[SET][1], d1, DH[2 * (Q)]); DH[2 * (Q) + 1] = mfma_u4(wv[SET][3], d1, DH[2 * (Q) + 1]);  \
+                             __builtin_amdgcn_sched_barrier(0); } while (0)
+#define GELU_PAIRS(I0) do { gelu_fb_pair(U, Gt, DG, I0); gelu_fb_pair(U, Gt, DG, (I0) + 2); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define MLP_BWD_TILE(TI, ODD, FIRST, EXTRA_AB)                                                   \
+        {                                                                                        \
+            const int ti = (TI), tt = (ti + rot) & 15;                                           \
+            uint32_t slot;                                                                       \
+            RINGA_STEP_X(src, slot, EXTRA_AB);                                                   \
+            STAMP(1);                                                                            \
+            f32x16 U = mma16a<4>(slot, fr, x, zero16());                                         \
+            add_vec(U, lb_up, tt, h);                                                            \
+            STAMP(2);                                                                            \
+            RINGA_STEP_X(src, slot, EXTRA_AB);                                                   \
+            STAMP(1);                                                                            \
+            f32x16 DG = mma16a<4>(slot, fr, t1, zero16());                                       \
+            STAMP(2);                                                                            \
+            f32x16 Gt;                                                                           \
+            if (FIRST) {                                                                         \
+                gelu_fwd_bwd16(U, Gt, DG);                                                       \
+            } else {                                                                             \
+                RINGA_STEP(src, slot);                                                           \
+                STAMP(1);                                                                        \
+                uint4 wv[2][4];                                                                  \
+                DH_READS(0, 0); DH_READS(1, 1);                                                  \
+                ALDS_WAITN(4); DH_MMAS(0, 0); DH_READS(0, 2); GELU_PAIRS(0);                     \
+                ALDS_WAITN(4); DH_MMAS(1, 1); DH_READS(1, 3); GELU_PAIRS(4);                     \
+                ALDS_WAITN(4); DH_MMAS(0, 2); GELU_PAIRS(8);                                     \
+                ALDS_WAITN(0); DH_MMAS(1, 3); GELU_PAIRS(12);                                    \
+            }                                                                                    \
+            acc_to_opnd(DG, d0, d1);                                                             \
+            STAMP(3);                                                                            \
+            stage_tile(stg_g, ODD, m, h, Gt);                                                    \
+            stage_tile(stg_du, ODD, m, h, DG);                                                   \
+            if (ODD) {                          /* the pair (tt-1, tt) is complete -> whole 128-B lines */ \
+                flush_lines<true>(stg_g, G, wrow0, 1024u, 64u * (tt - 1), lane);                 \
+                flush_lines<true>(stg_du, DU, wrow0, 1024u, 64u * (tt - 1), lane);               \
+            }                                                                                    \
+            STAMP(4);                                                                            \
+        }
+        MLP_BWD_TILE(0, 0, 1, 0)
+        MLP_BWD_TILE(1, 1, 0, 0)
+        for (int tp = 1; tp < 8; ++tp) {
+            MLP_BWD_TILE(2 * tp, 0, 0, 8)
+            MLP_BWD_TILE(2 * tp + 1, 1, 0, 0)
+        }
+        {   // d(x_hat) of the last tile
+            uint32_t slot;
+            RINGA_STEP_X(src, slot, 8);
             STAMP(1);
-            f32x16 U = mma16(slot, x, zero16(), m, h);
-            add_vec(U, lb_up, tt, h);
-            STAMP(2);
-            RING_STEP(src, slot);
-            STAMP(1);
-            f32x16 DG = mma16(slot, t1, zero16(), m, h);
-            STAMP(2);
-            f32x16 Gt;
-            if (MMFM_PROBE & 2) Gt = U; else gelu_fwd_bwd16(U, Gt, DG);
-            opnd d0, d1;
-            acc_to_opnd(DG, d0, d1);
-            STAMP(3);
-            RING_SYNC_WRITE(src);
-            STAMP(1);
-            stage_tile(stg_g, ti & 1, m, h, Gt);
-            stage_tile(stg_du, ti & 1, m, h, DG);
-            if ((ti & 1) && !(MMFM_PROBE & 1)) {              // uniform: the pair (tt-1, tt) is complete -> whole 128-B lines
-                flush_lines<true>(stg_g, G, wrow0, 1024u, 64u * (tt - 1), lane);
-                flush_lines<true>(stg_du, DU, wrow0, 1024u, 64u * (tt - 1), lane);
-            }
-            STAMP(4);
-            RING_FETCH(src, slot);
-#pragma unroll
-            for (int t2 = 0; t2 < 8; ++t2) {
-                DH[t2] = mfma(wfragB(slot, t2, 0, m, h), d0, DH[t2]);
-                DH[t2] = mfma(wfragB(slot, t2, 1, m, h), d1, DH[t2]);
-            }
+            uint4 wv[2][4];
+            DH_READS(0, 0); DH_READS(1, 1);
+            ALDS_WAITN(4); DH_MMAS(0, 0); DH_READS(0, 2);
+            ALDS_WAITN(4); DH_MMAS(1, 1); DH_READS(1, 3);
+            ALDS_WAITN(4); DH_MMAS(0, 2);
+            ALDS_WAITN(0); DH_MMAS(1, 3);
             STAMP(5);
         }
+#undef MLP_BWD_TILE
+#undef DH_READS
+#undef DH_MMAS
+#undef GELU_PAIRS
         // LayerNorm backward on the row: dx = dy + rstd * (dh - mean(dh) - x_hat * mean(dh * x_hat)); x_hat out of the stash, the four
         // dy line groups requested up front (the operand registers of the loop are dead here)
         Lines rl4[4];
@@ -286,6 +331,125 @@ __global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
     }
 }
 
+// The wave-pair forward on the asynchronous weight ring (rowchain.h): three 32 KB slots filled by LDS-DMA, chunk cc+2 requested while
+// chunk cc is multiplied.  With the register-staged ring (one chunk ahead) every ring step waited for its chunk's L2 round trip.
+// d.w_down must be the unit-permuted copy (mmfm_prep_entry.WpP): the DMA cannot permute on the way in.
+__global__ __launch_bounds__(NT8) void mlp_fwd8a_kernel(const mmfm_mlp_desc d) {
+    constexpr int NPAIR = 4;
+    constexpr int RING_B = RINGA_SLOTS * CHUNK2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // RING_B + 8 * STG_BYTES + NPAIR * 2 * 2048 + 768 * 4
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
+    const int role = wave >> 2, pw = wave & 3;
+    const int64_t npass = (d.R + 32 * NPAIR - 1) / (32 * NPAIR);
+    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
+    if (my_passes == 0) return;
+    const __amdgpu_buffer_rsrc_t rs_up = wbuf(d.w_up), rs_dn = wbuf(d.w_down);
+    const int rot = d.rotate ? (int)(blockIdx.x & 7) : 0;
+    auto src = [=](int g) {
+        const int idx = g & 15, u = ((idx >> 1) + rot) & 7;
+        AChunk2 c;
+        if (idx & 1) {
+            c.s[0].rs = rs_dn; c.s[0].off = (uint32_t)(64 * u) * 2u; c.s[0].ldb = 1024u; c.s[0].kind = 2;
+            c.s[1].rs = rs_dn; c.s[1].off = (uint32_t)(64 * u + 32) * 2u; c.s[1].ldb = 1024u; c.s[1].kind = 2;
+        } else {
+            c.s[0].rs = rs_up; c.s[0].off = (uint32_t)(64 * u) * 512u; c.s[0].ldb = 512u; c.s[0].kind = 0;
+            c.s[1].rs = rs_up; c.s[1].off = (uint32_t)(64 * u + 32) * 512u; c.s[1].ldb = 512u; c.s[1].kind = 0;
+        }
+        return c;
+    };
+    char* stg = smem + RING_B + wave * STG_BYTES;
+    char* exch = smem + RING_B + 8 * STG_BYTES + pw * 4096;            // [role][2 operands][64 lanes][16 B]
+    float* lb_up = reinterpret_cast<float*>(smem + RING_B + 8 * STG_BYTES + NPAIR * 4096);
+    float* lb_dn = lb_up + 512;
+    stage_vec(lb_up, d.b_up, 512, t, NT8);
+    stage_vec(lb_dn, d.b_down, 256, t, NT8);
+    const Drop dr = drop_init(d.drop);
+    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2);
+    const GBuf XH = gbuf(role == 0 ? d.xhat : nullptr, d.R * 512), RS = gbuf(role == 0 ? d.rstd : nullptr, d.R * 4);
+    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2;
+    const ALane<NT8> ring_al = alane_init<NT8>(t, 512u, 1024u);
+    const AFrag fr = afrag_init(m, h);
+    RINGA_DECL(NT8);
+    RINGA2_START((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem, my_passes * 16, src);
+    STAMP_DECL;
+    for (int pi = 0; pi < my_passes; ++pi) {
+        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NPAIR + pw) * 32);
+        const uint32_t row = wrow0 + m;
+        opnd x[16];
+        load_rows_lines<4>(stg, x, X, wrow0, ldxb, lane, m, h);
+        const float rs = ln_rows(x, d.eps);
+        store_rows_lines<4, true>(stg, XH, wrow0, 512u, lane, m, h, x);       // role 1: zero-sized buffer, dropped
+        st4f(RS, h == 0 ? row * 4u : 0xfffffff0u, rs);
+        f32x16 Yh[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) Yh[i] = zero16();
+        STAMP(0);
+        for (int ui = 0; ui < 8; ++ui) {
+            const int u = (ui + rot) & 7;
+            uint32_t slot;
+            RINGA2_STEP(src, slot);
+            STAMP(1);
+            f32x16 U = mma16a<4>(slot + (uint32_t)role * CHUNK, fr, x, zero16());
+            STAMP(2);
+            add_vec(U, lb_up, 2 * u + role, h);
+            gelu16(U);
+            opnd g0, g1;
+            acc_to_opnd(U, g0, g1);
+            *reinterpret_cast<uint4*>(exch + role * 2048 + lane * 16) = as_u4(g0);
+            *reinterpret_cast<uint4*>(exch + role * 2048 + 1024 + lane * 16) = as_u4(g1);
+            STAMP(3);
+            RINGA2_STEP(src, slot);                                             // its barrier publishes the pair's operands
+            STAMP(4);
+            const opnd p0 = as_opnd(*reinterpret_cast<const uint4*>(exch + (role ^ 1) * 2048 + lane * 16));
+            const opnd p1 = as_opnd(*reinterpret_cast<const uint4*>(exch + (role ^ 1) * 2048 + 1024 + lane * 16));
+            const opnd e0 = role == 0 ? g0 : p0, e1 = role == 0 ? g1 : p1;      // tile 2u   (even)
+            const opnd o0 = role == 0 ? p0 : g0, o1 = role == 0 ? p1 : g1;      // tile 2u+1 (odd)
+            // the immediate selects the output tile, the slot address the role's tile quartet; one group = the four operands of an output
+            // tile (both sub-blocks, both k-steps), two groups of reads in flight, counted waits
+            const uint32_t sq = slot + (uint32_t)role * (4u * 2048u);
+            uint4 wv[2][4];
+#define F8_READ(SET, J) do { ALDS_READ_B(wv[SET][0], sq, fr, J, 0); ALDS_READ_B(wv[SET][1], sq, fr, J, 1);                       \
+                             ALDS_READ_B(wv[SET][2], sq + CHUNK, fr, J, 0); ALDS_READ_B(wv[SET][3], sq + CHUNK, fr, J, 1); } while (0)
+            F8_READ(0, 0);
+            F8_READ(1, 1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (j < 3) ALDS_WAITN(4); else ALDS_WAITN(0);
+                Yh[j] = mfma_u4(wv[j & 1][0], e0, Yh[j]);
+                Yh[j] = mfma_u4(wv[j & 1][1], e1, Yh[j]);
+                Yh[j] = mfma_u4(wv[j & 1][2], o0, Yh[j]);
+                Yh[j] = mfma_u4(wv[j & 1][3], o1, Yh[j]);
+                if (j == 0) F8_READ(0, 2);
+                if (j == 1) F8_READ(1, 3);
+            }
+#undef F8_READ
+            STAMP(5);
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int lp = 2 * role + q;                                        // line pair = output tiles 2*lp, 2*lp+1
+            const Lines xl = fetch_lines(X, wrow0, ldxb, 128u * lp, lane);
+            stage_lines(stg, xl, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int t2 = 2 * lp + j;
+                add_vec(Yh[2 * q + j], lb_dn, t2, h);
+                if (dr.on()) {
+                    drop16(dr, Yh[2 * q + j], row, t2, h);
+                }
+                const f32x16 r = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) Yh[2 * q + j][i] += r[i];
+            }
+            stage_tile(stg, 0, m, h, Yh[2 * q]);
+            stage_tile(stg, 1, m, h, Yh[2 * q + 1]);
+            flush_lines<false>(stg, Y, wrow0, ldyb, 128u * lp, lane);
+        }
+        STAMP(6);
+    }
+    STAMP_FLUSH;
+}
+
 // dW = gamma * G + db x beta; dgamma = colsum(W * G); dbeta = W^T db.  Grid (K/32 column groups) x (NSPLIT row groups): every
 // block writes its dW rows and a partial (dgamma, dbeta) row; the LAST block of a column group (agent-scope ticket) sums the
 // NSPLIT partials in fixed order -> deterministic, one launch.
@@ -367,7 +531,18 @@ extern "C" int mmfm_mlp_fwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     const mmfm_mlp_desc d = *dp;
     if (int rc = check(d, false)) return rc;
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
-    hipLaunchKernelGGL(mlp_fwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), 0, (hipStream_t)stream, d);
+    static const int dma = [] { const char* e = getenv("MMFM_MLP_DMA"); return e ? atoi(e) : 1; }();
+    if (dma) {
+        constexpr int LDS_A = RINGA_SLOTS * CHUNK2 + 8 * STG_BYTES + 4 * 4096 + 768 * 4;
+        static bool opted = false;
+        if (!opted) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd8a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_A);
+            if (e != hipSuccess) return mmfm_set_error((int)e, "mmfm_mlp_fwd: hipFuncSetAttribute(%d B LDS): %s", LDS_A, hipGetErrorString(e));
+            opted = true;
+        }
+        hipLaunchKernelGGL(mlp_fwd8a_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), LDS_A, (hipStream_t)stream, d);
+    } else
+        hipLaunchKernelGGL(mlp_fwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), 0, (hipStream_t)stream, d);
     MMFM_LAUNCH_CHECK("mmfm_mlp_fwd");
     return 0;
 }
@@ -376,7 +551,14 @@ extern "C" int mmfm_mlp_bwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     const mmfm_mlp_desc d = *dp;
     if (int rc = check(d, true)) return rc;
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
-    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), 0, (hipStream_t)stream, d);
+    constexpr int LDS_B = RINGA_SLOTS * CHUNK + 2 * NW * STG_BYTES + 512 * 4 + NW * 4 * STG_BYTES;
+    static bool opted = false;
+    if (!opted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
+        if (e != hipSuccess) return mmfm_set_error((int)e, "mmfm_mlp_bwd: hipFuncSetAttribute(%d B LDS): %s", LDS_B, hipGetErrorString(e));
+        opted = true;
+    }
+    hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), LDS_B, (hipStream_t)stream, d);
     MMFM_LAUNCH_CHECK("mmfm_mlp_bwd");
     return 0;
 }

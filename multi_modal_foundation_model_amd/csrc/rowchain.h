@@ -232,6 +232,151 @@ __device__ __forceinline__ void stage_write2(const uint4 (&r)[2048 / NT], const 
     } while (0)
 #define RING2_STEP(SRC, SLOT) do { RING2_SYNC_WRITE(SRC); RING2_FETCH(SRC, SLOT); } while (0)
 
+// ---- asynchronous weight ring: THREE 16 KB slots filled by LDS-DMA (buffer_load_dwordx4 ... lds) -----------------------------
+// No staging registers, no ds_write pass, and chunk cc+2 is requested while chunk cc is multiplied (the register-staged rings above
+// pay a chunk's L2 latency or 16-32 staging registers for that distance).  The DMA and the operand reads are inline asm: hipcc orders
+// a plain LDS access behind EVERY LDS-DMA it knows to be in flight (s_waitcnt vmcnt(0)), which would drain the prefetch at each
+// bias / staging access of the loop.  Ordering is by hand instead:
+//   step cc:  s_waitcnt vmcnt(PP)   the PP = 1024 / NT loads of chunk cc+1 (issued last step) may stay in flight; vector-memory
+//                                   operations retire in order, so chunk cc's have landed (conservative when the kernel issued
+//                                   other loads / stores since: those and part of chunk cc+1 are waited for too)
+//             s_barrier             every wave's share of chunk cc is in LDS, and every wave is done reading chunk cc-1
+//             issue chunk cc+2      into the slot of chunk cc-1
+//             multiply chunk cc
+// The swizzles of the kind-0 / kind-2 images are applied to the per-lane SOURCE address (the LDS side of a DMA is lane-linear);
+// chunks whose operands are accumulator tiles need the PERM order in memory already: mmfm_prep_weights writes such copies.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+constexpr int RINGA_SLOTS = 3;
+struct AChunk {
+    __amdgpu_buffer_rsrc_t rs;     // the whole weight matrix (bf16, rows K-contiguous)
+    uint32_t off;                  // byte offset of the block's (row 0, k 0): wave-uniform
+    uint32_t ldb;                  // row stride in bytes
+    int kind;                      // 0: [32 rows][256 k]   2: [256 rows][32 k], 8-B units already in PERM order
+};
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wbuf(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+// per-thread source offsets: kind 0 - piece p = t + NT q sits at row p / 32, slot p % 32 and holds source chunk slot ^ (row & 15)
+// (two values: with NT / 32 = 8 rows per instruction, row & 15 alternates between r0 and r0 ^ 8); kind 2 - row p / 4, slot p % 4,
+// source chunk slot ^ ((row >> 2) & 3), the same for every q
+template <int NT> struct ALane { uint32_t k0[2], k2; };
+template <int NT>
+__device__ __forceinline__ ALane<NT> alane_init(int t, uint32_t ldb0, uint32_t ldb2) {
+    ALane<NT> a;
+    const uint32_t r0 = (uint32_t)t >> 5, c = (uint32_t)t & 31;
+    a.k0[0] = r0 * ldb0 + ((c ^ (r0 & 15)) << 4);
+    a.k0[1] = r0 * ldb0 + ((c ^ ((r0 + NT / 32) & 15)) << 4);
+    a.k2 = ((uint32_t)t >> 2) * ldb2 + ((((uint32_t)t & 3) ^ (((uint32_t)t >> 4) & 3)) << 4);
+    return a;
+}
+__device__ __forceinline__ void dma16(uint32_t lds_dst, uint32_t voff, __amdgpu_buffer_rsrc_t rs, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" :: "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff) : "memory", "m0");
+}
+// all NT threads: request one chunk into the slot at LDS byte address `slot` (wave-uniform)
+template <int NT>
+__device__ __forceinline__ void dma_chunk(uint32_t slot, const AChunk& c, const ALane<NT>& a, int wave) {
+    constexpr int PP = 1024 / NT;
+#pragma unroll
+    for (int q = 0; q < PP; ++q) {
+        const uint32_t dst = slot + (uint32_t)(q * NT * 16) + (uint32_t)wave * 1024u;
+        if (c.kind == 2) dma16(dst, a.k2, c.rs, c.off + (uint32_t)(q * (NT / 4)) * c.ldb);
+        else dma16(dst, a.k0[(NT == 256) ? (q & 1) : 0], c.rs, c.off + (uint32_t)(q * (NT / 32)) * c.ldb);
+    }
+}
+template <int N> __device__ __forceinline__ void vm_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
+//   RINGA_DECL(NT)                   locals
+//   RINGA_START(lds0, total, SRC)    chunks 0 and 1 requested (SRC(g) -> AChunk of the workgroup's g-th chunk)
+//   RINGA_STEP(SRC, SLOT)            wait + barrier; chunk cc+2 requested; SLOT = LDS byte address of chunk cc; ++cc
+#define RINGA_DECL(NTV) int ring_cc = 0, ring_last = 0; uint32_t ring_lds = 0; constexpr int RING_NT = (NTV)
+#define RINGA_START(LDS0, TOTAL, SRC)                                                        \
+    do {                                                                                     \
+        ring_lds = (LDS0); ring_last = (TOTAL) - 1;                                          \
+        dma_chunk<RING_NT>(ring_lds, SRC(0), ring_al, wave);                                 \
+        dma_chunk<RING_NT>(ring_lds + CHUNK, SRC(min(1, ring_last)), ring_al, wave);         \
+    } while (0)
+// RINGA_STEP_X: EXTRA = vector-memory operations (stores) the kernel is KNOWN to have issued since chunk cc's request, on top of
+// chunk cc+1's: they may stay in flight too.  (Only where that count is static; too large a value would let chunk cc itself
+// be outstanding.)
+#define RINGA_STEP(SRC, SLOT) RINGA_STEP_X(SRC, SLOT, 0)
+#define RINGA_STEP_X(SRC, SLOT, EXTRA)                                                       \
+    do {                                                                                     \
+        vm_wait_n<1024 / RING_NT + (EXTRA)>();                                               \
+        __builtin_amdgcn_s_barrier();                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        { int s2_ = (ring_cc + 2) % RINGA_SLOTS; dma_chunk<RING_NT>(ring_lds + (uint32_t)s2_ * CHUNK, SRC(min(ring_cc + 2, ring_last)), ring_al, wave); } \
+        SLOT = ring_lds + (uint32_t)(ring_cc % RINGA_SLOTS) * CHUNK;                         \
+        ++ring_cc;                                                                           \
+    } while (0)
+
+// the same ring with 32 KB chunks of two 16 KB sub-blocks (three slots = 96 KB): SRC(g) -> AChunk2
+struct AChunk2 { AChunk s[2]; };
+#define RINGA2_START(LDS0, TOTAL, SRC)                                                       \
+    do {                                                                                     \
+        ring_lds = (LDS0); ring_last = (TOTAL) - 1;                                          \
+        { const AChunk2 c_ = SRC(0); dma_chunk<RING_NT>(ring_lds, c_.s[0], ring_al, wave); dma_chunk<RING_NT>(ring_lds + CHUNK, c_.s[1], ring_al, wave); } \
+        { const AChunk2 c_ = SRC(min(1, ring_last)); dma_chunk<RING_NT>(ring_lds + CHUNK2, c_.s[0], ring_al, wave); dma_chunk<RING_NT>(ring_lds + CHUNK2 + CHUNK, c_.s[1], ring_al, wave); } \
+    } while (0)
+#define RINGA2_STEP(SRC, SLOT)                                                               \
+    do {                                                                                     \
+        vm_wait_n<2048 / RING_NT>();                                                         \
+        __builtin_amdgcn_s_barrier();                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        { const uint32_t d_ = ring_lds + (uint32_t)((ring_cc + 2) % RINGA_SLOTS) * CHUNK2; const AChunk2 c_ = SRC(min(ring_cc + 2, ring_last)); \
+          dma_chunk<RING_NT>(d_, c_.s[0], ring_al, wave); dma_chunk<RING_NT>(d_ + CHUNK, c_.s[1], ring_al, wave); } \
+        SLOT = ring_lds + (uint32_t)(ring_cc % RINGA_SLOTS) * CHUNK2;                        \
+        ++ring_cc;                                                                           \
+    } while (0)
+
+// operand reads of the asynchronous ring (inline asm, see above).  kind-0 image: operand S of lane (m, h) sits at
+//   m * 512 + (((2 S + h) ^ (m & 15)) << 4) = m * 512 + ((h ^ (m & 1)) << 4) + (((S & 7) << 5) ^ ((m & 14) << 4)) + (S >> 3) * 256
+// -> eight per-lane constants + an immediate; kind-2 image: tile t2, k-step s at (32 t2 + m) * 64 + (((2 s + h) ^ ((m >> 2) & 3)) << 4)
+// -> two per-lane constants + t2 * 2048.
+struct AFrag { uint32_t a[8], b[2]; };
+__device__ __forceinline__ AFrag afrag_init(int m, int h) {
+    AFrag f;
+    const uint32_t base = (uint32_t)m * 512u + ((uint32_t)(h ^ (m & 1)) << 4), A = (uint32_t)(m & 14) << 4;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) f.a[s] = base + (((uint32_t)s << 5) ^ A);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) f.b[s] = (uint32_t)m * 64u + ((uint32_t)((2 * s + h) ^ ((m >> 2) & 3)) << 4);
+    return f;
+}
+#define ALDS_READ(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define ALDS_WAIT0 do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+__device__ __forceinline__ f32x16 mfma_u4(uint4 a, opnd b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(opnd, a), b, c, 0, 0, 0); }
+// 16 MFMAs of a kind-0 chunk at LDS address `slot` against 16 operands; two sets of D weight operands, ping-pong, COUNTED waits:
+// two sets of reads are kept in flight and a group's MFMAs wait only for their own set (LDS returns in order), so the read
+// latency hides under the previous group's MFMAs (with lgkmcnt(0) after every group: 966 instead of ~600 cycles per chunk).
+// (No scalar loads may be pending here - they share the counter and return out of order; the kernels load their arguments up front.)
+#define ALDS_WAITN(N) do { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+template <int D = 8>
+__device__ __forceinline__ f32x16 mma16a(uint32_t slot, const AFrag& f, const opnd* x, f32x16 acc) {
+    constexpr int NG = 16 / D;
+    uint4 w[2][D];
+#define MMA16A_READ(SET, G)                                                                                  \
+    _Pragma("unroll") for (int s = 0; s < D; ++s) {                                                          \
+        const int S = (G) * D + s;                                                                           \
+        const uint32_t ad = f.a[S & 7] + slot;                                                               \
+        if (S < 8) ALDS_READ(w[SET][s], ad, 0); else ALDS_READ(w[SET][s], ad, 256);                          \
+    }
+    MMA16A_READ(0, 0)
+    if (NG > 1) { MMA16A_READ(1, 1) }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        if (g + 1 < NG) ALDS_WAITN(D); else ALDS_WAITN(0);
+#pragma unroll
+        for (int s = 0; s < D; ++s) acc = mfma_u4(w[g & 1][s], x[g * D + s], acc);
+        if (g + 2 < NG) { if (g & 1) { MMA16A_READ(1, g + 2) } else { MMA16A_READ(0, g + 2) } }
+    }
+#undef MMA16A_READ
+    return acc;
+}
+// weight operand (tile t2 of 8, k-step s of 2) of a kind-2 chunk at LDS address `slot`
+#define ALDS_READ_B(dst, slot, f, t2, s) do { const uint32_t ad_ = (f).b[s] + (slot); ALDS_READ(dst, ad_, (t2) * 2048); } while (0)
+#pragma clang diagnostic pop
+
 // weight operand of k-step S (0..15) from a [32][256] image: lane (i = lane & 31, h = lane >> 5)
 __device__ __forceinline__ opnd wfragA(const char* slot, int S, int i, int h) {
     return as_opnd(*reinterpret_cast<const uint4*>(slot + i * 512 + (((2 * S + h) ^ (i & 15)) << 4)));
@@ -426,6 +571,14 @@ __device__ __forceinline__ f32x16 mma16(const char* slot, const opnd* x, f32x16 
         for (int s = 0; s < DEPTH; ++s) acc = mfma(wf[s], x[DEPTH * part + s], acc);
     }
     return acc;
+}
+
+// one register pair (i, i+1; i even) of gelu_fwd_bwd16
+__device__ __forceinline__ void gelu_fb_pair(const f32x16& U, f32x16& G, f32x16& D, int i) {
+    mmfm_f32x2 a, g, dg; a.x = U[i]; a.y = U[i + 1];
+    gelu_both2(a, g, dg);
+    G[i] = g.x; G[i + 1] = g.y;
+    D[i] *= dg.x; D[i + 1] *= dg.y;
 }
 
 // ---- full-line global stores / loads through a per-wave LDS staging area -----------------------------------------------

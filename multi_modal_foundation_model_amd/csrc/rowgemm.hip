@@ -278,7 +278,7 @@ __global__ __launch_bounds__(512) void rowgemm_lnbwd8_kernel(const mmfm_rowgemm_
 }
 
 // ------------------------------------------------------------------------------------------------ weight preparation
-// One block per (entry, 32-row tile of W): Wp = bf16(W * gamma[k]) [N][K], WpT = its transpose [K][N],
+// One block per (entry, 32-row tile of W): Wp = bf16(W * gamma[k]) [N][K], WpT = its transpose [K][N] (WpP / WpTP: the same, unit-permuted),
 // bp[n] = bias[n] + sum_k W[n][k] * beta[k]  (the LayerNorm affine folded into the linear it feeds).
 __global__ __launch_bounds__(256) void prep_weights_kernel(const mmfm_prep_entry* __restrict__ E, int ne) {
     __shared__ float tile[32][33];
@@ -289,6 +289,10 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const mmfm_prep_entry
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     uint16_t* Wp = reinterpret_cast<uint16_t*>(en.Wp);
     uint16_t* WpT = reinterpret_cast<uint16_t*>(en.WpT);
+    uint16_t* WpP = reinterpret_cast<uint16_t*>(en.WpP);
+    uint16_t* WpTP = reinterpret_cast<uint16_t*>(en.WpTP);
+    // unit-permuted position of element i of a row: 4-element (8-byte) units 1 and 2 of every 16 swap places
+    auto perm = [](int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); };
     float dot[4] = {0.f, 0.f, 0.f, 0.f};
     for (int k0 = 0; k0 < en.K; k0 += 32) {
         const int k = k0 + tx;
@@ -301,14 +305,18 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const mmfm_prep_entry
             const float w = v * g;
             dot[j] = fmaf(v, bt, dot[j]);
             if (Wp && n < en.N && k < en.K) Wp[(size_t)n * en.K + k] = f2bf(w);
+            if (WpP && n < en.N && k < en.K) WpP[(size_t)n * en.K + perm(k)] = f2bf(w);
             tile[ty + 8 * j][tx] = w;
         }
         __syncthreads();
-        if (WpT) {
+        if (WpT || WpTP) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int kk = k0 + ty + 8 * j, n = n0 + tx;
-                if (kk < en.K && n < en.N) WpT[(size_t)kk * en.N + n] = f2bf(tile[tx][ty + 8 * j]);
+                if (kk < en.K && n < en.N) {
+                    if (WpT) WpT[(size_t)kk * en.N + n] = f2bf(tile[tx][ty + 8 * j]);
+                    if (WpTP) WpTP[(size_t)kk * en.N + perm(n)] = f2bf(tile[tx][ty + 8 * j]);
+                }
             }
         }
         __syncthreads();

@@ -349,16 +349,25 @@ class Engine:
         nW = sum(self.Pf(w + ".weight").numel() for w, _ in sites)
         nWp = sum(self.Pf(w + ".weight").numel() for w, ln in sites if ln)
         nb = sum(self.Pf(w + ".bias").numel() for w, ln in sites if ln)
+        # unit-permuted copies for the MLP kernels' LDS-DMA weight ring (include/mmfm.h: mmfm_prep_entry.WpP / WpTP)
+        nPm = sum(self.Pf(w + ".weight").numel() for w, _ in sites if w.endswith(".mlp.up_proj") or w.endswith(".mlp.down_proj"))
         WpT = torch.zeros(nW + 64, dtype=torch.bfloat16, device=self.device)
         Wp = torch.zeros(nWp + 64, dtype=torch.bfloat16, device=self.device)
+        Wpm = torch.zeros(nPm + 64, dtype=torch.bfloat16, device=self.device)
         bp = torch.zeros(nb + 64, dtype=torch.float32, device=self.device)
-        views, entries, oT, oW, ob = {}, [], 0, 0, 0
+        views, entries, oT, oW, ob, oP = {}, [], 0, 0, 0, 0
         for w, ln in sites:
             Wm = self.Pf(w + ".weight")
             N, Kd = Wm.shape
             e = dict(W=Wm, WpT=WpT[oT:oT + N * Kd].view(Kd, N))
             oT += N * Kd
             v = dict(WpT=e["WpT"])
+            if w.endswith(".mlp.up_proj"):          # backward: d(x_hat) += W_up^T[:, tile] . du, du an accumulator tile
+                e["WpTP"] = v["WpTP"] = Wpm[oP:oP + N * Kd].view(Kd, N)
+                oP += N * Kd
+            elif w.endswith(".mlp.down_proj"):      # forward: y += W_down[:, tile] . g, g an accumulator tile
+                e["WpP"] = v["WpP"] = Wpm[oP:oP + N * Kd].view(N, Kd)
+                oP += N * Kd
             if ln:
                 e.update(gamma=self.Pf(ln + ".weight"), beta=self.Pf(ln + ".bias"), bias=self.Pf(w + ".bias"),
                          Wp=Wp[oW:oW + N * Kd].view(N, Kd), bp=bp[ob:ob + N])
@@ -368,7 +377,7 @@ class Engine:
             views[w] = v
             entries.append(e)
         table, n, tiles = K.prep_table(entries, self.device)
-        self._prep = dict(table=table, n=n, tiles=tiles, v=views, keep=(WpT, Wp, bp, entries))
+        self._prep = dict(table=table, n=n, tiles=tiles, v=views, keep=(WpT, Wp, Wpm, bp, entries))
         return self._prep
 
     # ------------------------------------------------------------------ plan construction
@@ -608,7 +617,7 @@ class Engine:
             Xb = buf(tag + "/xb", (R, H))
             if F_MLP:
                 pu = prep["v"][p + ".mlp.up_proj"]
-                d_ = K.mlp_desc(R, x=X, w_up=pu["Wp"], b_up=pu["bp"], w_down=self.W(p + ".mlp.down_proj.weight"),
+                d_ = K.mlp_desc(R, x=X, w_up=pu["Wp"], b_up=pu["bp"], w_down=prep["v"][p + ".mlp.down_proj"]["WpP"],
                                 b_down=self.Pf(p + ".mlp.down_proj.bias"), drop=self._drop(tag + "/mlpdrop", dp), y=Xb,
                                 xhat=buf(tag + "/ln2/xh", (R, H)) if grad else None,
                                 rstd=buf(tag + "/ln2/rs", (R,), f32) if grad else None)
@@ -697,7 +706,7 @@ class Engine:
                 pu, pdn = prep["v"][p + ".mlp.up_proj"], prep["v"][p + ".mlp.down_proj"]
                 t1b, gb, dub = buf("d/t1m", (R, H)), buf("d/g", (R, I)), buf("d/du", (R, I))
                 d_ = K.mlp_desc(R, w_up=pu["Wp"], b_up=pu["bp"], drop=self._drop(tag + "/mlpdrop", dp), xhat=self.b[tag + "/ln2/xh"],
-                                rstd=self.b[tag + "/ln2/rs"], dy=dS, w_down_t=pdn["WpT"], w_up_t=pu["WpT"], t1=t1b, g=gb, du=dub, dx=dS)
+                                rstd=self.b[tag + "/ln2/rs"], dy=dS, w_down_t=pdn["WpT"], w_up_t=pu["WpTP"], t1=t1b, g=gb, du=dub, dx=dS)
                 K.mlp_bwd(d_, plan=plan)
                 dlin(plan, t1b, gb, p + ".mlp.down_proj", R, H, I)          # dW_down = t1^T g, db_down = colsum t1
                 dlin_ln(plan, dub, tag + "/ln2", p + ".mlp.up_proj", p + ".ln2", I)

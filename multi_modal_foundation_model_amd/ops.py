@@ -174,7 +174,7 @@ def collate_csr(B, max_T, max_N, pad_value, data, indices, indptr, indptr_off, n
 
 # ---------------------------------------------------------------------------------------------- row-owner fused kernels
 def prep_table(entries, device):
-    """entries: dicts with W (fp32 [N,K]) and optional gamma, beta, bias, Wp, WpT, bp tensors -> (device table, n, tiles, keep)."""
+    """entries: dicts with W (fp32 [N,K]) and optional gamma, beta, bias, Wp, WpT, bp, WpP, WpTP tensors -> (device table, n, tiles, keep)."""
     import numpy as np
     arr = (L.PrepEntry * len(entries))()
     tile0 = 0
@@ -183,6 +183,7 @@ def prep_table(entries, device):
         a = arr[i]
         a.W, a.gamma, a.beta, a.bias = P(e["W"]), P(e.get("gamma")), P(e.get("beta")), P(e.get("bias"))
         a.Wp, a.WpT, a.bp = P(e.get("Wp")), P(e.get("WpT")), P(e.get("bp"))
+        a.WpP, a.WpTP = P(e.get("WpP")), P(e.get("WpTP"))
         a.N, a.K, a.tile0 = N, Kd, tile0
         tile0 += (N + 31) // 32
     raw = np.frombuffer(bytes(arr), dtype=np.uint8).copy()

@@ -24,14 +24,14 @@ ops.attn_fwd(desc)
 def rnd(*s): return (torch.randn(*s, device="cuda") * 0.1).to(td)
 N, K = 512, 256
 x, dy = rnd(R, K), rnd(R, N)
-tiles = -(-N // 128) * -(-K // 128)
-S = max(1, min(R // 512, 768 // tiles, 128))
+tiles = Lb.lib().mmfm_gemm_dw_tiles(N, K, R)
+S = max(1, min(R // 512, 256 // tiles))
 kchunk = (-(-R // S) + 63) // 64 * 64
 S = -(-R // kchunk)
-slabs = torch.empty(S, N, K, device="cuda")
+slabs = torch.empty(S, N * K + N, device="cuda")
 w, dx = rnd(N, K), torch.empty(R, K, device="cuda", dtype=td)
 f_attn = lambda: ops.attn_bwd(desc)
-f_dw = lambda: [ops.gemm(dy, x, slabs, N, K, R, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk, slab_stride=N * K, c_f32=1) for _ in range(4)]
+f_dw = lambda: [ops.gemm(dy, x, slabs, N, K, R, lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk, slab_stride=N * K + N, c_f32=1, colsum=slabs.data_ptr() + 4 * N * K) for _ in range(4)]
 f_dx = lambda: [ops.gemm(dy, w, dx, R, K, N, lda=N, ldb=K, ldc=K, b_kcontig=0) for _ in range(4)]
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 def bench(fa, fb, reps=10):
@@ -43,8 +43,12 @@ def bench(fa, fb, reps=10):
             if par:
                 ev = torch.cuda.Event(); ev.record()
                 s1.wait_event(ev); s2.wait_event(ev)
-                with torch.cuda.stream(s1): fa()
-                with torch.cuda.stream(s2): fb()
+                if os.environ.get("OVL_DW_FIRST"):
+                    with torch.cuda.stream(s2): fb()
+                    with torch.cuda.stream(s1): fa()
+                else:
+                    with torch.cuda.stream(s1): fa()
+                    with torch.cuda.stream(s2): fb()
                 torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s2)
             else:
                 fa(); fb()

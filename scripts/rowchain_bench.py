@@ -27,7 +27,7 @@ def rnd(*s, sc=1.0): return (torch.randn(*s, device="cuda") * sc)
 def prep(W, g=None, b=None, bias=None):
     N, K = W.shape
     e = dict(W=W, gamma=g, beta=b, bias=bias, Wp=torch.empty(N, K, device="cuda", dtype=BF), WpT=torch.empty(K, N, device="cuda", dtype=BF),
-             bp=torch.empty(N, device="cuda"))
+             bp=torch.empty(N, device="cuda"), WpP=torch.empty(N, K, device="cuda", dtype=BF), WpTP=torch.empty(K, N, device="cuda", dtype=BF))
     tb, n, tiles = ops.prep_table([e], "cuda")
     ops.prep_weights(tb, n, tiles)
     return e
@@ -81,12 +81,12 @@ t_ln = t(lambda: ops.layernorm_fwd(x, g, bt, h, mean, rstd, R, 256))
 t_up = t(lambda: ops.gemm(h, Wub, gg, R, 512, 256, lda=256, ldb=256, ldc=512, bias=bu, pre_out=u, act=1))
 t_dn = t(lambda: ops.gemm(gg, Wdb, y, R, 256, 512, lda=512, ldb=512, ldc=256, bias=bd, drop=drop, residual=x, ldr=256))
 for p, dr in (("p=0.4", drop), ("p=0", None)):
-    d = ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd, drop=dr, rotate=ROT)
+    d = ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["WpP"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd, drop=dr, rotate=ROT)
     t_f = t(lambda: ops.mlp_fwd(d))
     print(f"MLP fwd {p:6s}     : un-fused {t_ln:6.1f} + {t_up:6.1f} + {t_dn:6.1f} = {t_ln + t_up + t_dn:6.1f} us   fused {t_f:6.1f} us  ({4 * R * 256 * 512 / t_f / 1e6:.0f} TF/s)")
 dy = rnd(R, 256).to(BF)
 t1, du, dx = torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 512, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF)
 for p, dr in (("p=0.4", drop), ("p=0", None)):
-    d = ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], drop=dr, xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpT"], t1=t1, g=gg, du=du, dx=dx, rotate=ROT)
+    d = ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], drop=dr, xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpTP"], t1=t1, g=gg, du=du, dx=dx, rotate=ROT)
     t_f = t(lambda: ops.mlp_bwd(d))
     print(f"MLP bwd {p:6s} (dX chain: recompute + dg + dh + LN bwd): fused {t_f:6.1f} us  ({6 * R * 256 * 512 / t_f / 1e6:.0f} TF/s)")

@@ -37,7 +37,8 @@ def check(a, b, rel, msg):
 def prep(ops, W, gamma=None, beta=None, bias=None, want_T=True):
     N, K = W.shape
     e = dict(W=W, gamma=gamma, beta=beta, bias=bias, Wp=torch.empty(N, K, device="cuda", dtype=BF),
-             WpT=torch.empty(K, N, device="cuda", dtype=BF) if want_T else None, bp=torch.empty(N, device="cuda"))
+             WpT=torch.empty(K, N, device="cuda", dtype=BF) if want_T else None, bp=torch.empty(N, device="cuda"),
+             WpP=torch.empty(N, K, device="cuda", dtype=BF), WpTP=torch.empty(K, N, device="cuda", dtype=BF))
     table, n, tiles = ops.prep_table([e], "cuda")
     ops.prep_weights(table, n, tiles)
     torch.cuda.synchronize()
@@ -50,6 +51,10 @@ def test_prep_weights_folds_layernorm_affine(ops):
     ref = (W * g).to(BF)
     assert torch.equal(e["Wp"], ref) and torch.equal(e["WpT"], ref.T.contiguous())
     torch.testing.assert_close(e["bp"], bias + W @ b, rtol=1e-5, atol=1e-5)
+    # unit-permuted copies (the order an accumulator tile holds its k index in): 4-element units 1 and 2 of every 16 swap places
+    def unit_perm(t):
+        return t.reshape(t.shape[0], -1, 4, 4)[:, :, [0, 2, 1, 3], :].reshape(t.shape)
+    assert torch.equal(e["WpP"], unit_perm(ref)) and torch.equal(e["WpTP"], unit_perm(ref.T.contiguous()))
     # several entries in one launch, ragged N
     es = [dict(W=rnd(n, k, seed=9 + i), Wp=torch.empty(n, k, device="cuda", dtype=BF), WpT=torch.empty(k, n, device="cuda", dtype=BF))
           for i, (n, k) in enumerate([(256, 512), (40, 256), (768, 256)])]
@@ -122,7 +127,7 @@ def mlp_setup(ops, R, seed=0):
 def test_mlp_forward(ops, R):
     x, Wu, bu, Wd, bd, g, bt, up, dn = mlp_setup(ops, R)
     y, xhat, rstd = torch.full((R + 2, 256), 3.0, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, device="cuda")
-    d = ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd)
+    d = ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["WpP"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd)
     ops.mlp_fwd(d)
     xd = x.double()
     h = F.layer_norm(xd, (256,), g.double(), bt.double(), 1e-5)
@@ -140,9 +145,9 @@ def test_mlp_forward_dropout_matches_backward_mask(ops):
     ops.rng_seed(state, 5)
     drop = ops.dropout(state, 9, p)
     y, xhat, rstd = torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, device="cuda")
-    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd, drop=drop))
+    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["WpP"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd, drop=drop))
     y0 = torch.empty_like(y)
-    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=y0, xhat=xhat, rstd=rstd))
+    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["WpP"], b_down=dn["bp"], y=y0, xhat=xhat, rstd=rstd))
     kept = (y.float() - x.float()) != 0
     assert 0.57 < kept.float().mean().item() < 0.63
     ref = torch.where(kept, (y0.float() - x.float()) / (1 - p), torch.zeros((), device="cuda"))
@@ -151,7 +156,7 @@ def test_mlp_forward_dropout_matches_backward_mask(ops):
     dy = torch.ones(R, 256, device="cuda", dtype=BF)
     t1, gg, du, dx = (torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 512, device="cuda", dtype=BF),
                       torch.empty(R, 512, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF))
-    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], drop=drop, xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpT"],
+    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], drop=drop, xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpTP"],
                              t1=t1, g=gg, du=du, dx=dx))
     sure = (y0.float() - x.float()).abs() > 0.25                      # where "y == x" can only mean "dropped", not "rounded away"
     assert sure.float().mean().item() > 0.3
@@ -163,11 +168,11 @@ def test_mlp_forward_dropout_matches_backward_mask(ops):
 def test_mlp_backward(ops, R):
     x, Wu, bu, Wd, bd, g, bt, up, dn = mlp_setup(ops, R, seed=40)
     y, xhat, rstd = torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, device="cuda")
-    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd))
+    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["WpP"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd))
     dy = rnd(R, 256, seed=77).to(BF)
     t1, gg, du, dx = (torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 512, device="cuda", dtype=BF),
                       torch.empty(R, 512, device="cuda", dtype=BF), torch.full((R + 1, 256), 5.0, device="cuda", dtype=BF))
-    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpT"],
+    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpTP"],
                              t1=t1, g=gg, du=du, dx=dx))
     assert torch.equal(t1, dy) and torch.all(dx[R:] == 5.0)
     xd = x.double().requires_grad_(True)
@@ -253,7 +258,7 @@ def test_full_size_mlp_forward_backward(ops):
     idx = sample_rows(R, seed=1)
     x, Wu, bu, Wd, bd, g, bt, up, dn = mlp_setup(ops, R, seed=60)
     y, xhat, rstd = torch.full((R + 2, 256), 3.0, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, device="cuda")
-    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd, rotate=1))
+    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["WpP"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd, rotate=1))
     assert torch.all(y[R:] == 3.0)
     xd = x[idx].double().requires_grad_(True)
     h = F.layer_norm(xd, (256,), g.double(), bt.double(), 1e-5)
@@ -262,13 +267,13 @@ def test_full_size_mlp_forward_backward(ops):
     out = xd + gl @ Wd.double().T + bd.double()
     check(y[idx], out.detach(), 6e-3, "full-size mlp fwd")
     ys = torch.empty(1000, 256, device="cuda", dtype=BF)
-    ops.mlp_fwd(ops.mlp_desc(1000, x=x[:1000], w_up=up["Wp"], b_up=up["bp"], w_down=dn["Wp"], b_down=dn["bp"], y=ys, xhat=torch.empty(1000, 256, device="cuda", dtype=BF),
+    ops.mlp_fwd(ops.mlp_desc(1000, x=x[:1000], w_up=up["Wp"], b_up=up["bp"], w_down=dn["WpP"], b_down=dn["bp"], y=ys, xhat=torch.empty(1000, 256, device="cuda", dtype=BF),
                              rstd=torch.empty(1000, device="cuda")))
     assert torch.equal(ys, y[:1000])
     dy = rnd(R, 256, seed=77).to(BF)
     t1, gg, du, dx = (torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 512, device="cuda", dtype=BF),
                       torch.empty(R, 512, device="cuda", dtype=BF), torch.full((R + 1, 256), 5.0, device="cuda", dtype=BF))
-    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpT"], t1=t1, g=gg, du=du, dx=dx, rotate=1))
+    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpTP"], t1=t1, g=gg, du=du, dx=dx, rotate=1))
     assert torch.equal(t1, dy) and torch.all(dx[R:] == 5.0)
     u.retain_grad(); gl.retain_grad()
     out.backward(dy[idx].double())
