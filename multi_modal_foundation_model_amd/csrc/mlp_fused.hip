@@ -133,27 +133,32 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
         {                                                                                        \
             const int ti = (TI), tt = (ti + rot) & 15;                                           \
             uint32_t slot;                                                                       \
-            RINGA_STEP_X(src, slot, EXTRA_AB);                                                   \
-            STAMP(1);                                                                            \
-            f32x16 U = mma16a<4>(slot, fr, x, zero16());                                         \
+            f32x16 U, DG;                                                                        \
+            {                                                                                    \
+                RINGA_SYNC(src, slot, EXTRA_AB);                                                 \
+                STAMP(1);                                                                        \
+                U = mma16a<4>(slot, fr, x, zero16(), [&](int g_) { RINGA_PIECE(g_); });          \
+            }                                                                                    \
             add_vec(U, lb_up, tt, h);                                                            \
             STAMP(2);                                                                            \
-            RINGA_STEP_X(src, slot, EXTRA_AB);                                                   \
-            STAMP(1);                                                                            \
-            f32x16 DG = mma16a<4>(slot, fr, t1, zero16());                                       \
+            {                                                                                    \
+                RINGA_SYNC(src, slot, EXTRA_AB);                                                 \
+                STAMP(1);                                                                        \
+                DG = mma16a<4>(slot, fr, t1, zero16(), [&](int g_) { RINGA_PIECE(g_); });        \
+            }                                                                                    \
             STAMP(2);                                                                            \
             f32x16 Gt;                                                                           \
             if (FIRST) {                                                                         \
                 gelu_fwd_bwd16(U, Gt, DG);                                                       \
             } else {                                                                             \
-                RINGA_STEP(src, slot);                                                           \
+                RINGA_SYNC(src, slot, 0);                                                        \
                 STAMP(1);                                                                        \
                 uint4 wv[2][4];                                                                  \
                 DH_READS(0, 0); DH_READS(1, 1);                                                  \
-                ALDS_WAITN(4); DH_MMAS(0, 0); DH_READS(0, 2); GELU_PAIRS(0);                     \
-                ALDS_WAITN(4); DH_MMAS(1, 1); DH_READS(1, 3); GELU_PAIRS(4);                     \
-                ALDS_WAITN(4); DH_MMAS(0, 2); GELU_PAIRS(8);                                     \
-                ALDS_WAITN(0); DH_MMAS(1, 3); GELU_PAIRS(12);                                    \
+                ALDS_WAITN(4); DH_MMAS(0, 0); RINGA_PIECE(0); DH_READS(0, 2); GELU_PAIRS(0);     \
+                ALDS_WAITN(4); DH_MMAS(1, 1); RINGA_PIECE(1); DH_READS(1, 3); GELU_PAIRS(4);     \
+                ALDS_WAITN(4); DH_MMAS(0, 2); RINGA_PIECE(2); GELU_PAIRS(8);                     \
+                ALDS_WAITN(0); DH_MMAS(1, 3); RINGA_PIECE(3); GELU_PAIRS(12);                    \
             }                                                                                    \
             acc_to_opnd(DG, d0, d1);                                                             \
             STAMP(3);                                                                            \
@@ -173,14 +178,14 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
         }
         {   // d(x_hat) of the last tile
             uint32_t slot;
-            RINGA_STEP_X(src, slot, 8);
+            RINGA_SYNC(src, slot, 8);
             STAMP(1);
             uint4 wv[2][4];
             DH_READS(0, 0); DH_READS(1, 1);
-            ALDS_WAITN(4); DH_MMAS(0, 0); DH_READS(0, 2);
-            ALDS_WAITN(4); DH_MMAS(1, 1); DH_READS(1, 3);
-            ALDS_WAITN(4); DH_MMAS(0, 2);
-            ALDS_WAITN(0); DH_MMAS(1, 3);
+            ALDS_WAITN(4); DH_MMAS(0, 0); RINGA_PIECE(0); DH_READS(0, 2);
+            ALDS_WAITN(4); DH_MMAS(1, 1); RINGA_PIECE(1); DH_READS(1, 3);
+            ALDS_WAITN(4); DH_MMAS(0, 2); RINGA_PIECE(2);
+            ALDS_WAITN(0); DH_MMAS(1, 3); RINGA_PIECE(3);
             STAMP(5);
         }
 #undef MLP_BWD_TILE
@@ -387,9 +392,12 @@ __global__ __launch_bounds__(NT8) void mlp_fwd8a_kernel(const mmfm_mlp_desc d) {
         for (int ui = 0; ui < 8; ++ui) {
             const int u = (ui + rot) & 7;
             uint32_t slot;
-            RINGA2_STEP(src, slot);
-            STAMP(1);
-            f32x16 U = mma16a<4>(slot + (uint32_t)role * CHUNK, fr, x, zero16());
+            f32x16 U;
+            {
+                RINGA2_SYNC(src, slot);
+                STAMP(1);
+                U = mma16a<4>(slot + (uint32_t)role * CHUNK, fr, x, zero16(), [&](int g_) { RINGA2_PIECE(g_); });
+            }
             STAMP(2);
             add_vec(U, lb_up, 2 * u + role, h);
             gelu16(U);
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(NT8) void mlp_fwd8a_kernel(const mmfm_mlp_desc d) {
             *reinterpret_cast<uint4*>(exch + role * 2048 + lane * 16) = as_u4(g0);
             *reinterpret_cast<uint4*>(exch + role * 2048 + 1024 + lane * 16) = as_u4(g1);
             STAMP(3);
-            RINGA2_STEP(src, slot);                                             // its barrier publishes the pair's operands
+            RINGA2_SYNC(src, slot);                                             // its barrier publishes the pair's operands
             STAMP(4);
             const opnd p0 = as_opnd(*reinterpret_cast<const uint4*>(exch + (role ^ 1) * 2048 + lane * 16));
             const opnd p1 = as_opnd(*reinterpret_cast<const uint4*>(exch + (role ^ 1) * 2048 + 1024 + lane * 16));
@@ -419,6 +427,8 @@ __global__ __launch_bounds__(NT8) void mlp_fwd8a_kernel(const mmfm_mlp_desc d) {
                 Yh[j] = mfma_u4(wv[j & 1][1], e1, Yh[j]);
                 Yh[j] = mfma_u4(wv[j & 1][2], o0, Yh[j]);
                 Yh[j] = mfma_u4(wv[j & 1][3], o1, Yh[j]);
+                __builtin_amdgcn_sched_barrier(0);
+                RINGA2_PIECE(j);
                 if (j == 0) F8_READ(0, 2);
                 if (j == 1) F8_READ(1, 3);
             }

@@ -284,6 +284,14 @@ __device__ __forceinline__ void dma_chunk(uint32_t slot, const AChunk& c, const 
         else dma16(dst, a.k0[(NT == 256) ? (q & 1) : 0], c.rs, c.off + (uint32_t)(q * (NT / 32)) * c.ldb);
     }
 }
+// one of the PP = 1024 / NT requests of a chunk (q = 0 .. PP-1): lets a kernel place them between its MFMA groups - a request costs
+// ~130 issue cycles, which disappear in the shadow of four MFMAs but add up to a quarter of a ring step when issued in a row
+template <int NT>
+__device__ __forceinline__ void dma_piece(uint32_t slot, const AChunk& c, const ALane<NT>& a, int wave, int q) {
+    const uint32_t dst = slot + (uint32_t)(q * NT * 16) + (uint32_t)wave * 1024u;
+    if (c.kind == 2) dma16(dst, a.k2, c.rs, c.off + (uint32_t)(q * (NT / 4)) * c.ldb);
+    else dma16(dst, a.k0[(NT == 256) ? (q & 1) : 0], c.rs, c.off + (uint32_t)(q * (NT / 32)) * c.ldb);
+}
 template <int N> __device__ __forceinline__ void vm_wait_n() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
 //   RINGA_DECL(NT)                   locals
@@ -329,6 +337,28 @@ struct AChunk2 { AChunk s[2]; };
         ++ring_cc;                                                                           \
     } while (0)
 
+// Split form: RINGA_SYNC waits / synchronises and names the chunk to request (ring_nc -> slot ring_nd); the kernel then places
+// RINGA_PIECE(q), q = 0 .. PP-1, between its MFMA groups.  All PP pieces must be issued before the next RINGA_SYNC.
+#define RINGA_SYNC(SRC, SLOT, EXTRA)                                                         \
+        vm_wait_n<1024 / RING_NT + (EXTRA)>();                                               \
+        __builtin_amdgcn_s_barrier();                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        const AChunk ring_nc = SRC(min(ring_cc + 2, ring_last));                             \
+        const uint32_t ring_nd = ring_lds + (uint32_t)((ring_cc + 2) % RINGA_SLOTS) * CHUNK; \
+        SLOT = ring_lds + (uint32_t)(ring_cc % RINGA_SLOTS) * CHUNK;                         \
+        ++ring_cc
+#define RINGA_PIECE(Q) dma_piece<RING_NT>(ring_nd, ring_nc, ring_al, wave, (Q))
+// ... and for the 32 KB chunks: pieces q = 0 .. 2 PP - 1 (sub-block q / PP)
+#define RINGA2_SYNC(SRC, SLOT)                                                               \
+        vm_wait_n<2048 / RING_NT>();                                                         \
+        __builtin_amdgcn_s_barrier();                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        const AChunk2 ring_nc = SRC(min(ring_cc + 2, ring_last));                            \
+        const uint32_t ring_nd = ring_lds + (uint32_t)((ring_cc + 2) % RINGA_SLOTS) * CHUNK2; \
+        SLOT = ring_lds + (uint32_t)(ring_cc % RINGA_SLOTS) * CHUNK2;                        \
+        ++ring_cc
+#define RINGA2_PIECE(Q) dma_piece<RING_NT>(ring_nd + (uint32_t)((Q) / (1024 / RING_NT)) * CHUNK, ring_nc.s[(Q) / (1024 / RING_NT)], ring_al, wave, (Q) % (1024 / RING_NT))
+
 // operand reads of the asynchronous ring (inline asm, see above).  kind-0 image: operand S of lane (m, h) sits at
 //   m * 512 + (((2 S + h) ^ (m & 15)) << 4) = m * 512 + ((h ^ (m & 1)) << 4) + (((S & 7) << 5) ^ ((m & 14) << 4)) + (S >> 3) * 256
 // -> eight per-lane constants + an immediate; kind-2 image: tile t2, k-step s at (32 t2 + m) * 64 + (((2 s + h) ^ ((m >> 2) & 3)) << 4)
@@ -351,8 +381,10 @@ __device__ __forceinline__ f32x16 mfma_u4(uint4 a, opnd b, f32x16 c) { return __
 // latency hides under the previous group's MFMAs (with lgkmcnt(0) after every group: 966 instead of ~600 cycles per chunk).
 // (No scalar loads may be pending here - they share the counter and return out of order; the kernels load their arguments up front.)
 #define ALDS_WAITN(N) do { asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N) : "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
-template <int D = 8>
-__device__ __forceinline__ f32x16 mma16a(uint32_t slot, const AFrag& f, const opnd* x, f32x16 acc) {
+// `after(g)` runs behind the MFMAs of group g (the kernels issue one ring request there)
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+template <int D = 8, typename HOOK = NoHook>
+__device__ __forceinline__ f32x16 mma16a(uint32_t slot, const AFrag& f, const opnd* x, f32x16 acc, HOOK after = HOOK()) {
     constexpr int NG = 16 / D;
     uint4 w[2][D];
 #define MMA16A_READ(SET, G)                                                                                  \
@@ -368,6 +400,8 @@ __device__ __forceinline__ f32x16 mma16a(uint32_t slot, const AFrag& f, const op
         if (g + 1 < NG) ALDS_WAITN(D); else ALDS_WAITN(0);
 #pragma unroll
         for (int s = 0; s < D; ++s) acc = mfma_u4(w[g & 1][s], x[g * D + s], acc);
+        __builtin_amdgcn_sched_barrier(0);
+        after(g);
         if (g + 2 < NG) { if (g & 1) { MMA16A_READ(1, g + 2) } else { MMA16A_READ(0, g + 2) } }
     }
 #undef MMA16A_READ
