@@ -307,27 +307,28 @@ int mmfm_rowgemm(const mmfm_rowgemm_desc* d, mmfm_stream stream);
 
 /* The MLP block in one launch (mm_utils.py:42-52 behind ln2, encoder_embeddings.py:114, decoder_embeddings.py:145):
  *   fwd:  y = x + dropout( down( gelu_erf( up( layernorm(x) ) ) ) )        the 512-wide intermediate never leaves the CU
- *         w_up / b_up are the prepared (gamma / beta folded) [512][256] / [512]; w_down bf16 [256][512]; x_hat / rstd are
- *         written for the backward.
+ *         w_up / b_up are the prepared (gamma / beta folded) [512][256] / [512]; w_down = bf16 [256][512], UNIT-PERMUTED
+ *         (mmfm_prep_entry.WpP of down_proj: the weights reach LDS by DMA, which cannot permute); x_hat / rstd are written for the backward.
  *   bwd:  recomputes u = up(x_hat) and g = gelu(u) from the saved x_hat instead of loading them, and produces
  *         t1 = dropout'(dy)                      [R][256]   (operand of dW_down = t1^T g, db_down = colsum t1)
  *         g                                      [R][512]
  *         du = (t1 . W_down) * gelu'(u)          [R][512]   (operand of G_up = du^T x_hat, db_up = colsum du)
- *         dx = dy + LayerNorm'(du . Wp_up)       [R][256]   (LayerNorm backward in registers; needs w_up_t = Wp_up^T, w_down_t = W_down^T)
+ *         dx = dy + LayerNorm'(du . Wp_up)       [R][256]   (LayerNorm backward in registers; needs w_up_t = Wp_up^T UNIT-PERMUTED =
+ *                                                            mmfm_prep_entry.WpTP of up_proj, w_down_t = W_down^T)
  *   Weight / LayerNorm-parameter gradients then follow from mmfm_gemm (dW slabs) + mmfm_ln_linear_grad. */
 typedef struct {
     int64_t R;
     const void* x; int ldx;           /* fwd: residual stream in (bf16 [R][256]) */
     float eps;
     const void* w_up; const float* b_up;
-    const void* w_down; const float* b_down;
+    const void* w_down; const float* b_down;      /* w_down: unit-permuted (WpP) */
     mmfm_dropout drop;
     void* y; int ldy;
     void* xhat; float* rstd;          /* fwd: out;  bwd: in */
     /* backward only */
     const void* dy; int lddy;
     const void* w_down_t;             /* bf16 [512][256] */
-    const void* w_up_t;               /* bf16 [256][512] (prepared) */
+    const void* w_up_t;               /* bf16 [256][512] (prepared, unit-permuted: WpTP) */
     void* t1; void* g; void* du;
     void* dx; int lddx;
     int rotate;                       /* 1: workgroups start at different intermediate tiles (spreads the concurrent L2 reads) */

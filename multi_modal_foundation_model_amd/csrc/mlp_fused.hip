@@ -121,7 +121,7 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
         // (hipcc would cluster them in front of the vector work: one wave per SIMD, nothing else to fill the MFMA pipe's shadow), so
         // the ring carries  up(0) dg(0) | up(1) dg(1) dh(0) | ... | up(15) dg(15) dh(14) | dh(15).
         // ODD tiles complete a pair of g / du tiles: their 16 line stores leave at the end of the iteration, and the next two ring
-        // steps may therefore leave eight more operations in flight (RINGA_STEP_X).
+        // steps may therefore leave eight more operations in flight (the EXTRA argument of RINGA_SYNC).
         opnd d0, d1;                                         // du operands of the previous tile
 #define DH_READS(SET, Q) do { ALDS_READ_B(wv[SET][0], slot, fr, 2 * (Q), 0); ALDS_READ_B(wv[SET][1], slot, fr, 2 * (Q), 1);          \
                               ALDS_READ_B(wv[SET][2], slot, fr, 2 * (Q) + 1, 0); ALDS_READ_B(wv[SET][3], slot, fr, 2 * (Q) + 1, 1); } while (0)
@@ -242,104 +242,13 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
 // one-wave-per-tile forward, 300 us against 257 us, and a wave-pair backward, 539 us against 478 us for the one-wave kernel above.)
 constexpr int NT8 = 512;
 
-__global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
-    constexpr int NPAIR = 4;
-    __shared__ __attribute__((aligned(16))) char smem[2 * CHUNK2 + 8 * STG_BYTES + NPAIR * 2 * 2048 + 768 * 4];
-    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
-    const int role = wave >> 2, pw = wave & 3;
-    const int64_t npass = (d.R + 32 * NPAIR - 1) / (32 * NPAIR);
-    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
-    if (my_passes == 0) return;
-    const uint16_t* Wup = reinterpret_cast<const uint16_t*>(d.w_up);
-    const uint16_t* Wdn = reinterpret_cast<const uint16_t*>(d.w_down);
-    const int rot = d.rotate ? (int)(blockIdx.x & 7) : 0;
-    auto src = [=](int g) {
-        const int idx = g & 15, u = ((idx >> 1) + rot) & 7;
-        WChunk2 c;
-        if (idx & 1) {
-            c.s[0].base = Wdn + 64 * u; c.s[0].ld = 512; c.s[0].kind = 2;
-            c.s[1].base = Wdn + 64 * u + 32; c.s[1].ld = 512; c.s[1].kind = 2;
-        } else {
-            c.s[0].base = Wup + (size_t)(64 * u) * 256; c.s[0].ld = 256; c.s[0].kind = 0;
-            c.s[1].base = Wup + (size_t)(64 * u + 32) * 256; c.s[1].ld = 256; c.s[1].kind = 0;
-        }
-        return c;
-    };
-    char* stg = smem + 2 * CHUNK2 + wave * STG_BYTES;
-    char* exch = smem + 2 * CHUNK2 + 8 * STG_BYTES + pw * 4096;            // [role][2 operands][64 lanes][16 B]
-    float* lb_up = reinterpret_cast<float*>(smem + 2 * CHUNK2 + 8 * STG_BYTES + NPAIR * 4096);
-    float* lb_dn = lb_up + 512;
-    stage_vec(lb_up, d.b_up, 512, t, NT8);
-    stage_vec(lb_dn, d.b_down, 256, t, NT8);
-    const Drop dr = drop_init(d.drop);
-    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2);
-    const GBuf XH = gbuf(role == 0 ? d.xhat : nullptr, d.R * 512), RS = gbuf(role == 0 ? d.rstd : nullptr, d.R * 4);
-    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2;
-    RING2_DECL(NT8);
-    RING2_START(smem, my_passes * 16, src);
-    for (int pi = 0; pi < my_passes; ++pi) {
-        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NPAIR + pw) * 32);
-        const uint32_t row = wrow0 + m;
-        opnd x[16];
-        load_rows_lines<4>(stg, x, X, wrow0, ldxb, lane, m, h);
-        const float rs = ln_rows(x, d.eps);
-        store_rows_lines<4, true>(stg, XH, wrow0, 512u, lane, m, h, x);       // role 1: zero-sized buffer, dropped
-        st4f(RS, h == 0 ? row * 4u : 0xfffffff0u, rs);
-        f32x16 Yh[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) Yh[i] = zero16();
-        for (int ui = 0; ui < 8; ++ui) {
-            const int u = (ui + rot) & 7;
-            const char* slot;
-            RING2_STEP(src, slot);
-            f32x16 U = mma16<4>(slot + role * CHUNK, x, zero16(), m, h);
-            add_vec(U, lb_up, 2 * u + role, h);
-            gelu16(U);
-            opnd g0, g1;
-            acc_to_opnd(U, g0, g1);
-            *reinterpret_cast<uint4*>(exch + role * 2048 + lane * 16) = as_u4(g0);
-            *reinterpret_cast<uint4*>(exch + role * 2048 + 1024 + lane * 16) = as_u4(g1);
-            RING2_STEP(src, slot);                                              // its barrier publishes the pair's operands
-            const opnd p0 = as_opnd(*reinterpret_cast<const uint4*>(exch + (role ^ 1) * 2048 + lane * 16));
-            const opnd p1 = as_opnd(*reinterpret_cast<const uint4*>(exch + (role ^ 1) * 2048 + 1024 + lane * 16));
-            const opnd e0 = role == 0 ? g0 : p0, e1 = role == 0 ? g1 : p1;      // tile 2u   (even)
-            const opnd o0 = role == 0 ? p0 : g0, o1 = role == 0 ? p1 : g1;      // tile 2u+1 (odd)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int t2 = 4 * role + j;
-                Yh[j] = mfma(wfragB(slot, t2, 0, m, h), e0, Yh[j]);
-                Yh[j] = mfma(wfragB(slot, t2, 1, m, h), e1, Yh[j]);
-                Yh[j] = mfma(wfragB(slot + CHUNK, t2, 0, m, h), o0, Yh[j]);
-                Yh[j] = mfma(wfragB(slot + CHUNK, t2, 1, m, h), o1, Yh[j]);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int lp = 2 * role + q;                                        // line pair = output tiles 2*lp, 2*lp+1
-            const Lines xl = fetch_lines(X, wrow0, ldxb, 128u * lp, lane);
-            stage_lines(stg, xl, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int t2 = 2 * lp + j;
-                add_vec(Yh[2 * q + j], lb_dn, t2, h);
-                if (dr.on()) {
-                    drop16(dr, Yh[2 * q + j], row, t2, h);
-                }
-                const f32x16 r = unstage_tile(stg, j, m, h);
-#pragma unroll
-                for (int i = 0; i < 16; ++i) Yh[2 * q + j][i] += r[i];
-            }
-            stage_tile(stg, 0, m, h, Yh[2 * q]);
-            stage_tile(stg, 1, m, h, Yh[2 * q + 1]);
-            flush_lines<false>(stg, Y, wrow0, ldyb, 128u * lp, lane);
-        }
-    }
-}
-
-// The wave-pair forward on the asynchronous weight ring (rowchain.h): three 32 KB slots filled by LDS-DMA, chunk cc+2 requested while
-// chunk cc is multiplied.  With the register-staged ring (one chunk ahead) every ring step waited for its chunk's L2 round trip.
+// The weights stream through the asynchronous ring (rowchain.h): three 32 KB slots filled by LDS-DMA, chunk cc+2 requested - one
+// request behind each MFMA group - while chunk cc is multiplied (register-staged ring, one chunk ahead: 251 us; this: 213 us).
 // d.w_down must be the unit-permuted copy (mmfm_prep_entry.WpP): the DMA cannot permute on the way in.
-__global__ __launch_bounds__(NT8) void mlp_fwd8a_kernel(const mmfm_mlp_desc d) {
+// Measured and not kept (round 3): a producer / consumer split of the pair (one wave LayerNorm + up-projection + GELU, the other the
+// down-projection one ring step behind): 222 / 199 us with and without dropout against 216 / 206 - the producer's GELU (1,300 cycles
+// per tile, as long as 40 MFMAs) becomes the critical path and the consumer idles at the barrier.
+__global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
     constexpr int NPAIR = 4;
     constexpr int RING_B = RINGA_SLOTS * CHUNK2;
     extern __shared__ __attribute__((aligned(16))) char smem[];       // RING_B + 8 * STG_BYTES + NPAIR * 2 * 2048 + 768 * 4
@@ -541,18 +450,16 @@ extern "C" int mmfm_mlp_fwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     const mmfm_mlp_desc d = *dp;
     if (int rc = check(d, false)) return rc;
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
-    static const int dma = [] { const char* e = getenv("MMFM_MLP_DMA"); return e ? atoi(e) : 1; }();
-    if (dma) {
+    {
         constexpr int LDS_A = RINGA_SLOTS * CHUNK2 + 8 * STG_BYTES + 4 * 4096 + 768 * 4;
         static bool opted = false;
         if (!opted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd8a_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_A);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_A);
             if (e != hipSuccess) return mmfm_set_error((int)e, "mmfm_mlp_fwd: hipFuncSetAttribute(%d B LDS): %s", LDS_A, hipGetErrorString(e));
             opted = true;
         }
-        hipLaunchKernelGGL(mlp_fwd8a_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), LDS_A, (hipStream_t)stream, d);
-    } else
-        hipLaunchKernelGGL(mlp_fwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), 0, (hipStream_t)stream, d);
+        hipLaunchKernelGGL(mlp_fwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), LDS_A, (hipStream_t)stream, d);
+    }
     MMFM_LAUNCH_CHECK("mmfm_mlp_fwd");
     return 0;
 }

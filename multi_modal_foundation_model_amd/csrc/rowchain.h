@@ -16,7 +16,9 @@
 //     order inside a 16-deep step is permuted (element j of lane half h = k 8*(j>>2) + 4*h + (j&3)); the weight chunks
 //     that multiply such operands are staged with the same permutation (PERM images below).
 //
-// Weight ring: two 16 KB LDS slots per workgroup.  Chunk c+2 is in flight from L2 in staging registers while chunk c+1
+// Weight rings.  The row GEMMs (rowgemm.hip: two workgroups per CU, HBM-bound) use the register-staged ring described next; the MLP
+// kernels (mlp_fused.hip: one workgroup per CU, every latency exposed) the asynchronous LDS-DMA ring further down.
+// Register-staged ring: two 16 KB LDS slots per workgroup.  Chunk c+2 is in flight from L2 in staging registers while chunk c+1
 // is written to the free slot and chunk c is multiplied; ONE __syncthreads() per chunk (16 MFMAs per wave).  All loads
 // are ordinary loads, so hipcc's own s_waitcnt bookkeeping orders everything - and to let it COUNT (vmcnt(N), not
 // vmcnt(0): the vector-memory counter retires in order, so a conservative wait for a weight chunk would also wait for
@@ -146,43 +148,6 @@ __device__ __forceinline__ void stage_write(const uint4 (&r)[1024 / NT], int kin
     } while (0)
 #define RING_STEP(SRC, SLOT) do { RING_SYNC_WRITE(SRC); RING_FETCH(SRC, SLOT); } while (0)
 
-// Prefetch distance TWO (measured with the stamped MLP kernel, scripts/probe/mlp_stamp.py: with distance one a chunk's L2 latency
-// - about one step long under load - sat in every step: 1,200-1,500 cycles per ring step, half of the kernel).  Two register
-// sets, selected by the PARITY of the chunk index at compile time (call sites alternate _E / _O, every pass has an even number
-// of chunks) so the code stays straight-line: at step cc chunk cc+1 (fetched two steps ago) is written to the free slot and
-// chunk cc+3 goes in flight into the set that just emptied.
-#define RINGD_DECL(NTV) uint4 ring_r0[1024 / (NTV)], ring_r1[1024 / (NTV)]; int ring_cc = 0, ring_last = 0; char* ring_smem = nullptr; constexpr int RING_NT = (NTV)
-#define RINGD_START(SMEM, TOTAL, SRC)                                                        \
-    do {                                                                                     \
-        ring_smem = (SMEM); ring_last = (TOTAL) - 1;                                         \
-        { const WChunk c0_ = SRC(0); stage_load<RING_NT>(ring_r0, c0_, t); stage_write<RING_NT>(ring_r0, c0_.kind, ring_smem, t); } \
-        { const WChunk c1_ = SRC(min(1, ring_last)); stage_load<RING_NT>(ring_r1, c1_, t); } \
-        { const WChunk c2_ = SRC(min(2, ring_last)); stage_load<RING_NT>(ring_r0, c2_, t); } \
-    } while (0)
-#ifndef RING_BARRIER_STAMP
-#define RING_BARRIER_STAMP
-#endif
-#define RINGD_SYNC_WRITE_(SRC, SET)                                                          \
-    do {                                                                                     \
-        __syncthreads();                                                                     \
-        RING_BARRIER_STAMP;                                                                  \
-        const WChunk cw_ = SRC(min(ring_cc + 1, ring_last));                                 \
-        stage_write<RING_NT>(SET, cw_.kind, ring_smem + ((ring_cc + 1) & 1) * CHUNK, t);     \
-    } while (0)
-#define RINGD_FETCH_(SRC, SLOT, SET)                                                         \
-    do {                                                                                     \
-        const WChunk cf_ = SRC(min(ring_cc + 3, ring_last));                                 \
-        stage_load<RING_NT>(SET, cf_, t);                                                    \
-        SLOT = ring_smem + (ring_cc & 1) * CHUNK;                                            \
-        ++ring_cc;                                                                           \
-    } while (0)
-#define RINGD_SYNC_WRITE_E(SRC) RINGD_SYNC_WRITE_(SRC, ring_r1)
-#define RINGD_SYNC_WRITE_O(SRC) RINGD_SYNC_WRITE_(SRC, ring_r0)
-#define RINGD_FETCH_E(SRC, SLOT) RINGD_FETCH_(SRC, SLOT, ring_r1)
-#define RINGD_FETCH_O(SRC, SLOT) RINGD_FETCH_(SRC, SLOT, ring_r0)
-#define RINGD_STEP_E(SRC, SLOT) do { RINGD_SYNC_WRITE_E(SRC); RINGD_FETCH_E(SRC, SLOT); } while (0)
-#define RINGD_STEP_O(SRC, SLOT) do { RINGD_SYNC_WRITE_O(SRC); RINGD_FETCH_O(SRC, SLOT); } while (0)
-
 // The same ring with 32 KB chunks made of two 16 KB sub-blocks (possibly of different matrices): twice the MFMAs per barrier.
 struct WChunk2 { WChunk s[2]; };
 constexpr int CHUNK2 = 2 * CHUNK;
@@ -296,7 +261,7 @@ template <int N> __device__ __forceinline__ void vm_wait_n() { asm volatile("s_w
 
 //   RINGA_DECL(NT)                   locals
 //   RINGA_START(lds0, total, SRC)    chunks 0 and 1 requested (SRC(g) -> AChunk of the workgroup's g-th chunk)
-//   RINGA_STEP(SRC, SLOT)            wait + barrier; chunk cc+2 requested; SLOT = LDS byte address of chunk cc; ++cc
+//   RINGA_SYNC / RINGA_PIECE         one ring step (below)
 #define RINGA_DECL(NTV) int ring_cc = 0, ring_last = 0; uint32_t ring_lds = 0; constexpr int RING_NT = (NTV)
 #define RINGA_START(LDS0, TOTAL, SRC)                                                        \
     do {                                                                                     \
@@ -304,20 +269,6 @@ template <int N> __device__ __forceinline__ void vm_wait_n() { asm volatile("s_w
         dma_chunk<RING_NT>(ring_lds, SRC(0), ring_al, wave);                                 \
         dma_chunk<RING_NT>(ring_lds + CHUNK, SRC(min(1, ring_last)), ring_al, wave);         \
     } while (0)
-// RINGA_STEP_X: EXTRA = vector-memory operations (stores) the kernel is KNOWN to have issued since chunk cc's request, on top of
-// chunk cc+1's: they may stay in flight too.  (Only where that count is static; too large a value would let chunk cc itself
-// be outstanding.)
-#define RINGA_STEP(SRC, SLOT) RINGA_STEP_X(SRC, SLOT, 0)
-#define RINGA_STEP_X(SRC, SLOT, EXTRA)                                                       \
-    do {                                                                                     \
-        vm_wait_n<1024 / RING_NT + (EXTRA)>();                                               \
-        __builtin_amdgcn_s_barrier();                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        { int s2_ = (ring_cc + 2) % RINGA_SLOTS; dma_chunk<RING_NT>(ring_lds + (uint32_t)s2_ * CHUNK, SRC(min(ring_cc + 2, ring_last)), ring_al, wave); } \
-        SLOT = ring_lds + (uint32_t)(ring_cc % RINGA_SLOTS) * CHUNK;                         \
-        ++ring_cc;                                                                           \
-    } while (0)
-
 // the same ring with 32 KB chunks of two 16 KB sub-blocks (three slots = 96 KB): SRC(g) -> AChunk2
 struct AChunk2 { AChunk s[2]; };
 #define RINGA2_START(LDS0, TOTAL, SRC)                                                       \
@@ -326,19 +277,11 @@ struct AChunk2 { AChunk s[2]; };
         { const AChunk2 c_ = SRC(0); dma_chunk<RING_NT>(ring_lds, c_.s[0], ring_al, wave); dma_chunk<RING_NT>(ring_lds + CHUNK, c_.s[1], ring_al, wave); } \
         { const AChunk2 c_ = SRC(min(1, ring_last)); dma_chunk<RING_NT>(ring_lds + CHUNK2, c_.s[0], ring_al, wave); dma_chunk<RING_NT>(ring_lds + CHUNK2 + CHUNK, c_.s[1], ring_al, wave); } \
     } while (0)
-#define RINGA2_STEP(SRC, SLOT)                                                               \
-    do {                                                                                     \
-        vm_wait_n<2048 / RING_NT>();                                                         \
-        __builtin_amdgcn_s_barrier();                                                        \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
-        { const uint32_t d_ = ring_lds + (uint32_t)((ring_cc + 2) % RINGA_SLOTS) * CHUNK2; const AChunk2 c_ = SRC(min(ring_cc + 2, ring_last)); \
-          dma_chunk<RING_NT>(d_, c_.s[0], ring_al, wave); dma_chunk<RING_NT>(d_ + CHUNK, c_.s[1], ring_al, wave); } \
-        SLOT = ring_lds + (uint32_t)(ring_cc % RINGA_SLOTS) * CHUNK2;                        \
-        ++ring_cc;                                                                           \
-    } while (0)
-
-// Split form: RINGA_SYNC waits / synchronises and names the chunk to request (ring_nc -> slot ring_nd); the kernel then places
-// RINGA_PIECE(q), q = 0 .. PP-1, between its MFMA groups.  All PP pieces must be issued before the next RINGA_SYNC.
+// A ring step: RINGA_SYNC(SRC, SLOT, EXTRA) waits / synchronises (SLOT = LDS byte address of chunk cc; ++cc) and names the chunk to
+// request (ring_nc -> slot ring_nd); the kernel then places RINGA_PIECE(q), q = 0 .. PP-1, between its MFMA groups.  All PP pieces
+// must be issued before the next RINGA_SYNC.  EXTRA = vector-memory operations (stores) the kernel is KNOWN to have issued since
+// chunk cc's request, on top of chunk cc+1's: they may stay in flight too (only where that count is static; too large a value
+// would let chunk cc itself be outstanding).
 #define RINGA_SYNC(SRC, SLOT, EXTRA)                                                         \
         vm_wait_n<1024 / RING_NT + (EXTRA)>();                                               \
         __builtin_amdgcn_s_barrier();                                                        \
