@@ -87,6 +87,11 @@ typedef struct {
                         M*N + M elements finishes weight and bias gradient together. */
 } mmfm_gemm_desc;
 int mmfm_gemm(const mmfm_gemm_desc* d, mmfm_stream stream);
+/* Two independent products, same results as two mmfm_gemm calls.  Two bf16 weight-gradient descriptors (the dY^T X form with split-K
+ * slabs) run as ONE launch, each on its share of the CUs: the caller then sizes their split counts so that
+ * tiles(a) * splits(a) + tiles(b) * splits(b) = 256 with the first term a multiple of 8 (mmfm_gemm_dw_tiles) - each product makes half
+ * the slabs it would make alone.  The weight gradients of two linears whose dY are both at hand (MLP up / down, attention qkv / out_proj). */
+int mmfm_gemm_pair(const mmfm_gemm_desc* a, const mmfm_gemm_desc* b, mmfm_stream stream);
 
 /* dst[i] (+)= sum_s src[s*slab_stride + i], fp32, deterministic order.  `src` is scratch: it may be
  * clobbered (a tall-skinny reduction first sums groups of slabs in place). */

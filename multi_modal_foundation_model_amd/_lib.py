@@ -86,6 +86,7 @@ _PROTOS = {
     "mmfm_rng_seed": (C.c_int, [_vp, C.c_uint64, _vp]),
     "mmfm_rng_advance": (C.c_int, [_vp, _vp]),
     "mmfm_gemm": (C.c_int, [C.POINTER(GemmDesc), _vp]),
+    "mmfm_gemm_pair": (C.c_int, [_vp, _vp, _vp]),
     "mmfm_gemm_dw_tiles": (C.c_int, [_i, _i, _i]),
     "mmfm_reduce_slabs": (C.c_int, [_vp, _vp, _i64, _i, _i64, _i, _vp]),
     "mmfm_reduce_slabs_multi": (C.c_int, [_vp, _i, _i, _vp]),

@@ -295,9 +295,10 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const T* __restrict__ x, i
 
 int mmfm_gemm_bf16_launch(const mmfm_gemm_desc* d, hipStream_t st);  // gemm_bf16.hip
 
-extern "C" int mmfm_gemm(const mmfm_gemm_desc* dp, mmfm_stream stream) {
+// argument checks and normalisation shared by mmfm_gemm and mmfm_gemm_pair (d = *dp on success)
+static int gemm_check(const mmfm_gemm_desc* dp, mmfm_gemm_desc& d) {
     MMFM_REQUIRE(dp != nullptr, "mmfm_gemm: null descriptor");
-    mmfm_gemm_desc d = *dp;
+    d = *dp;
     MMFM_REQUIRE(d.dtype == MMFM_F32 || d.dtype == MMFM_BF16, "mmfm_gemm: bad dtype %d", d.dtype);
     MMFM_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "mmfm_gemm: bad shape M=%d N=%d K=%d", d.M, d.N, d.K);
     MMFM_REQUIRE(d.A && d.B && d.C, "mmfm_gemm: null operand");
@@ -320,6 +321,14 @@ extern "C" int mmfm_gemm(const mmfm_gemm_desc* dp, mmfm_stream stream) {
     }
     MMFM_REQUIRE(!d.residual || d.ldr >= d.N, "mmfm_gemm: ldr too small");
     MMFM_REQUIRE(!d.colsum || (d.dtype == MMFM_BF16 && d.a_kcontig == 0), "mmfm_gemm: colsum needs dtype bf16 and a_kcontig == 0");
+    return 0;
+}
+
+int mmfm_gemm_dw_pair_launch(const mmfm_gemm_desc* a, const mmfm_gemm_desc* b, hipStream_t st);   // gemm_dw.hip
+
+extern "C" int mmfm_gemm(const mmfm_gemm_desc* dp, mmfm_stream stream) {
+    mmfm_gemm_desc d;
+    if (int rc = gemm_check(dp, d)) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (d.dtype == MMFM_BF16) return mmfm_gemm_bf16_launch(&d, st);
 
@@ -332,6 +341,21 @@ extern "C" int mmfm_gemm(const mmfm_gemm_desc* dp, mmfm_stream stream) {
     else hipLaunchKernelGGL((gemm_f32_kernel<false, false>), grid, block, 0, st, d, vecA, vecB);
     MMFM_LAUNCH_CHECK("mmfm_gemm(f32)");
     return 0;
+}
+
+// Two independent GEMMs.  Two bf16 weight-gradient launches that the streaming kernel takes run as ONE launch, each on its share of the
+// CUs; anything else is issued one after the other - same results either way.
+extern "C" int mmfm_gemm_pair(const mmfm_gemm_desc* ap, const mmfm_gemm_desc* bp, mmfm_stream stream) {
+    mmfm_gemm_desc a, b;
+    if (int rc = gemm_check(ap, a)) return rc;
+    if (int rc = gemm_check(bp, b)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.dtype == MMFM_BF16 && b.dtype == MMFM_BF16) {
+        const int rc = mmfm_gemm_dw_pair_launch(&a, &b, st);
+        if (rc != -1000) return rc;
+    }
+    if (int rc = mmfm_gemm(ap, stream)) return rc;
+    return mmfm_gemm(bp, stream);
 }
 
 // Several reductions in one launch: block b owns one 256-float chunk of one entry (found by bisection over the entries' chunk0

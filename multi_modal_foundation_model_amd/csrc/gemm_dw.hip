@@ -73,8 +73,20 @@ __device__ __forceinline__ opnd mk_opnd(u32x2 lo, u32x2 hi) {
 #define LDS_WAIT0 do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 template <int N> __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+// Two independent weight gradients in ONE launch (mmfm_gemm_pair): workgroups [0, first) take problem p.a, the rest p.b, one item each.
+// Each problem then makes half as many K-slabs as it would alone on the whole chip: half the slab bytes written here and read by the
+// reductions (256 x 128 KB per launch either way), one launch less.
+struct DwPair {
+    DwArgs a, b;
+    int first;           // items of problem a (a multiple of 8: the XCD-aware item order works per problem); 0 = single launch of a
+};
+
 template <int TN, int BK>
-__global__ __launch_bounds__(DNT) void gemm_dw_kernel(const DwArgs a) {
+__global__ __launch_bounds__(DNT) void gemm_dw_kernel(const DwPair pr) {
+    const bool second = pr.first > 0 && (int)blockIdx.x >= pr.first;
+    const DwArgs& a = second ? pr.b : pr.a;
+    const int w0 = second ? (int)blockIdx.x - pr.first : (int)blockIdx.x;
+    const int wstep = pr.first > 0 ? (1 << 30) : (int)gridDim.x;
     typedef Geo<TN, BK> G;
     constexpr int NLW = 4;                                       // every wave issues its quarter of the DMA loads
     constexpr int NST = G::NST, NJ = G::NJ, RBB = TN * 2;       // B image row bytes
@@ -107,7 +119,7 @@ __global__ __launch_bounds__(DNT) void gemm_dw_kernel(const DwArgs a) {
     ones4[0] = ones4[1] = ones4[2] = ones4[3] = 0x3F803F80u;
     const opnd ones = __builtin_bit_cast(opnd, ones4);
 
-    for (int w = blockIdx.x; w < a.items; w += gridDim.x) {
+    for (int w = w0; w < a.items; w += wstep) {
         const int item = xcd_order(w, a.items);           // = z * ntiles + tile: neighbours on an XCD share the K-slab
         const int z = item / a.ntiles, tile = item - z * a.ntiles;
         const int m0 = (tile / a.tiles_n) * TM, n0 = (tile % a.tiles_n) * TN;
@@ -229,8 +241,18 @@ __global__ __launch_bounds__(DNT) void gemm_dw_kernel(const DwArgs a) {
     }
 }
 
+template <int TN>
+DwArgs make_args(const mmfm_gemm_desc& d) {
+    DwArgs a;
+    a.d = d;
+    a.tiles_n = cdiv(d.N, TN);
+    a.ntiles = cdiv(d.M, TM) * a.tiles_n;
+    a.items = a.ntiles * std::max(1, d.splits);
+    return a;
+}
+
 template <int TN, int BK>
-int launch(const mmfm_gemm_desc& d, hipStream_t st) {
+int launch(const mmfm_gemm_desc& d, const mmfm_gemm_desc* d2, hipStream_t st) {
     typedef Geo<TN, BK> G;
     static bool opted = false;
     if (!opted) {
@@ -238,12 +260,17 @@ int launch(const mmfm_gemm_desc& d, hipStream_t st) {
         if (e != hipSuccess) return mmfm_set_error((int)e, "mmfm_gemm(bf16, dW stream): hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
         opted = true;
     }
-    DwArgs a;
-    a.d = d;
-    a.tiles_n = cdiv(d.N, TN);
-    a.ntiles = cdiv(d.M, TM) * a.tiles_n;
-    a.items = a.ntiles * std::max(1, d.splits);
-    hipLaunchKernelGGL((gemm_dw_kernel<TN, BK>), dim3(std::min(a.items, 256)), dim3(DNT), G::LDS, st, a);
+    DwPair p;
+    p.a = make_args<TN>(d);
+    p.b = p.a;
+    p.first = 0;
+    int grid = std::min(p.a.items, 256);
+    if (d2) {
+        p.b = make_args<TN>(*d2);
+        p.first = p.a.items;
+        grid = p.a.items + p.b.items;
+    }
+    hipLaunchKernelGGL((gemm_dw_kernel<TN, BK>), dim3(grid), dim3(DNT), G::LDS, st, p);
     MMFM_LAUNCH_CHECK("mmfm_gemm(bf16, dW stream)");
     return 0;
 }
@@ -261,18 +288,34 @@ static bool dw_wide(int N, int K) {
 // number of (tile) items per K-slab the streaming kernel makes of an [M, N] gradient over K rows (the engine sizes the split count with it)
 extern "C" int mmfm_gemm_dw_tiles(int M, int N, int K) { return cdiv(M, TM) * cdiv(N, dw_wide(N, K) ? 256 : 128); }
 
+static bool dw_eligible(const mmfm_gemm_desc& d) {
+    static const int on = [] { const char* e = getenv("MMFM_GEMM_DW"); return e ? atoi(e) : 1; }();
+    const bool f32out = d.c_f32 || d.splits > 1;
+    if (!on || d.dtype != MMFM_BF16 || !f32out || d.a_kcontig || d.b_kcontig) return false;
+    if (d.bias || d.pre_out || d.gradmul_pre || d.residual || d.act || (d.drop.p > 0.f)) return false;
+    // 16-B pieces: rows 16-B aligned; a ragged last piece (M or N not a multiple of 8) must still lie inside its row (padded leading dimension) -
+    // the columns it adds are computed and dropped
+    if (d.lda % 8 || d.ldb % 8 || d.lda < (d.M + 7) / 8 * 8 || d.ldb < (d.N + 7) / 8 * 8 || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15) || ((uintptr_t)d.C & 3)) return false;
+    if (d.splits > 1 && (d.kchunk % 64 || d.kchunk <= 0)) return false;
+    if (((int64_t)d.K + 9 * 64) * std::max(d.lda, d.ldb) * 2 >= (int64_t)1 << 31) return false;          // 32-bit buffer offsets, ring run-out included
+    return true;
+}
+
 // returns -1000 when the launch belongs to the general kernel of gemm_bf16.hip
 int mmfm_gemm_dw_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     const mmfm_gemm_desc& d = *dp;
-    static const int on = [] { const char* e = getenv("MMFM_GEMM_DW"); return e ? atoi(e) : 1; }();
-    const bool f32out = d.c_f32 || d.splits > 1;
-    if (!on || d.dtype != MMFM_BF16 || !f32out || d.a_kcontig || d.b_kcontig) return -1000;
-    if (d.bias || d.pre_out || d.gradmul_pre || d.residual || d.act || (d.drop.p > 0.f)) return -1000;
-    // 16-B pieces: rows 16-B aligned; a ragged last piece (M or N not a multiple of 8) must still lie inside its row (padded leading dimension) -
-    // the columns it adds are computed and dropped
-    if (d.lda % 8 || d.ldb % 8 || d.lda < (d.M + 7) / 8 * 8 || d.ldb < (d.N + 7) / 8 * 8 || ((uintptr_t)d.A & 15) || ((uintptr_t)d.B & 15) || ((uintptr_t)d.C & 3)) return -1000;
-    if (d.splits > 1 && (d.kchunk % 64 || d.kchunk <= 0)) return -1000;
-    if (((int64_t)d.K + 9 * 64) * std::max(d.lda, d.ldb) * 2 >= (int64_t)1 << 31) return -1000;          // 32-bit buffer offsets, ring run-out included
-    const bool wide = dw_wide(d.N, d.K);
-    return wide ? launch<256, 32>(d, st) : launch<128, 32>(d, st);
+    if (!dw_eligible(d)) return -1000;
+    return dw_wide(d.N, d.K) ? launch<256, 32>(d, nullptr, st) : launch<128, 32>(d, nullptr, st);
+}
+
+// both descriptors in one launch when both belong to the streaming kernel with the same tile width, every item fits the grid once and the
+// first problem's item count is a multiple of 8; -1000 otherwise (the caller then issues them one after the other)
+int mmfm_gemm_dw_pair_launch(const mmfm_gemm_desc* ap, const mmfm_gemm_desc* bp, hipStream_t st) {
+    const mmfm_gemm_desc &a = *ap, &b = *bp;
+    if (!dw_eligible(a) || !dw_eligible(b)) return -1000;
+    const bool wide = dw_wide(a.N, a.K);
+    if (wide != dw_wide(b.N, b.K)) return -1000;
+    const int ia = mmfm_gemm_dw_tiles(a.M, a.N, a.K) * std::max(1, a.splits), ib = mmfm_gemm_dw_tiles(b.M, b.N, b.K) * std::max(1, b.splits);
+    if (ia % 8 || ia + ib > 512) return -1000;
+    return wide ? launch<256, 32>(a, &b, st) : launch<128, 32>(a, &b, st);
 }

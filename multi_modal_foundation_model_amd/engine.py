@@ -439,6 +439,7 @@ class Engine:
             S, _ = self._dw_split(mm, nn, R)
             max_slab = max(max_slab, S * _align(mm * nn + mm))
         slab = buf("ws/slab", (max_slab,), f32)
+        slab2 = buf("ws/slab2", (max_slab,), f32)          # a deferred weight-gradient GEMM's slabs, paired with the next one (mmfm_gemm_pair)
         # launch-bound regime (R <= 8192, the reference's batch of 16): every dW GEMM keeps its own slab region and ONE
         # mmfm_reduce_slabs_multi per backward segment sums them all (66 reductions of ~7 us each otherwise)
         batch_red = R <= 8192 and os.environ.get("MMFM_BATCH_REDUCE", "1") != "0"
@@ -466,7 +467,31 @@ class Engine:
 
         used_wt: list = []
 
-        def dlin(plan, dY, X, wname, Mr, N, Kd, dX=None, ldx=None, **kw):
+        # Two weight gradients whose operands are both at hand (MLP down / up, attention out_proj / qkv) leave in ONE launch
+        # (mmfm_gemm_pair): `dlin(..., defer=True)` parks the first, the next `dlin_ln` takes it along; `flush_deferred` issues a
+        # parked one alone.  Each product then makes half as many K-slabs (csrc/gemm_dw.hip).
+        pair_ok = code == L.BF16 and not batch_red and os.environ.get("MMFM_DW_PAIR", "1") != "0" and os.environ.get("MMFM_GEMM_DW", "1") != "0"
+        deferred: list = []
+
+        def pair_splits(Na, Ka, Nb, Kb, Mr):
+            ta, tb = L.lib().mmfm_gemm_dw_tiles(Na, Ka, Mr), L.lib().mmfm_gemm_dw_tiles(Nb, Kb, Mr)
+            ia = 256 * (Na + Ka) / (Na + Ka + Nb + Kb)
+            Sa = max(1, int(ia) // ta)
+            while Sa > 1 and (ta * Sa) % 8:
+                Sa -= 1
+            Sb = max(1, (256 - ta * Sa) // tb)
+            out = []
+            for S in (Sa, Sb):
+                kchunk = _align(-(-Mr // max(1, min(S, Mr // 512))), 64)
+                out += [-(-Mr // kchunk), kchunk]
+            return out
+
+        def flush_deferred(plan):
+            if deferred:
+                a = deferred.pop()
+                dlin(plan, a["dY"], a["X"], a["wname"], a["Mr"], a["N"], a["Kd"])
+
+        def dlin(plan, dY, X, wname, Mr, N, Kd, dX=None, ldx=None, defer=False, **kw):
             """Backward of Y[Mr,N] = X[Mr,Kd] @ W[N,Kd]^T + b:  dW, db into G;  dX = dY @ W (optional, fused epilogue).
             ldx = row stride of X when its rows are padded."""
             S, kchunk = self._dw_split(N, Kd, Mr, ldn=ldx)
@@ -476,6 +501,10 @@ class Engine:
             # gradient sits right behind the weight gradient in the flat buffer one slab reduction finishes both
             fused = code == L.BF16
             adjacent = fused and gb.data_ptr() == gw.data_ptr() + 4 * N * Kd
+            if defer and pair_ok and S > 1 and adjacent and dX is None and ldx == Kd:
+                flush_deferred(plan)
+                deferred.append(dict(dY=dY, X=X, wname=wname, Mr=Mr, N=N, Kd=Kd))
+                return
             if S == 1:
                 K.gemm(dY, X, gw, N, Kd, Mr, lda=N, ldb=ldx, ldc=Kd, a_kcontig=0, b_kcontig=0, dtype=code, c_f32=1,
                        colsum=gb if fused else None, plan=plan)
@@ -554,7 +583,19 @@ class Engine:
             """Gradients of a LayerNorm-fed linear and of that LayerNorm's affine from G = dY^T x_hat (mmfm_ln_linear_grad)."""
             S, kchunk = self._dw_split(N, H, R)
             xh = self.b[tag + "/xh"]
-            if S == 1:
+            if deferred and S > 1 and deferred[-1]["Mr"] == R:
+                a = deferred.pop()
+                Na, Ka = a["N"], a["Kd"]
+                Sa, kca, Sb, kcb = pair_splits(Na, Ka, N, H, R)
+                stra, strb = _align(Na * Ka + Na), _align(N * H + N)
+                da = K.gemm_desc(a["dY"], a["X"], slab2, Na, Ka, R, lda=Na, ldb=Ka, ldc=Ka, a_kcontig=0, b_kcontig=0, splits=Sa, kchunk=kca,
+                                 slab_stride=stra, dtype=code, c_f32=1, colsum=slab2.data_ptr() + 4 * Na * Ka)
+                db_ = K.gemm_desc(dYt, xh, slab, N, H, R, lda=N, ldb=H, ldc=H, a_kcontig=0, b_kcontig=0, splits=Sb, kchunk=kcb,
+                                  slab_stride=strb, dtype=code, c_f32=1, colsum=slab.data_ptr() + 4 * N * H)
+                K.gemm_pair(da, db_, plan=plan)
+                K.reduce_slabs(self.Gv(a["wname"] + ".weight"), slab2, Na * Ka + Na, Sa, stra, plan=plan)
+                K.reduce_slabs(gdb, slab, N * H + N, Sb, strb, plan=plan)
+            elif S == 1:
                 K.gemm(dYt, xh, gdb, N, H, R, lda=N, ldb=H, ldc=H, a_kcontig=0, b_kcontig=0, dtype=code, c_f32=1,
                        colsum=gdb.data_ptr() + 4 * N * H, plan=plan)
             else:
@@ -708,8 +749,9 @@ class Engine:
                 d_ = K.mlp_desc(R, w_up=pu["Wp"], b_up=pu["bp"], drop=self._drop(tag + "/mlpdrop", dp), xhat=self.b[tag + "/ln2/xh"],
                                 rstd=self.b[tag + "/ln2/rs"], dy=dS, w_down_t=pdn["WpT"], w_up_t=pu["WpTP"], t1=t1b, g=gb, du=dub, dx=dS)
                 K.mlp_bwd(d_, plan=plan)
-                dlin(plan, t1b, gb, p + ".mlp.down_proj", R, H, I)          # dW_down = t1^T g, db_down = colsum t1
+                dlin(plan, t1b, gb, p + ".mlp.down_proj", R, H, I, defer=True)     # dW_down = t1^T g, db_down = colsum t1
                 dlin_ln(plan, dub, tag + "/ln2", p + ".mlp.up_proj", p + ".ln2", I)
+                flush_deferred(plan)
                 return
             dSd = dS
             if dp > 0:                                                       # mm_utils.py:52 dropout(down_proj(.))
@@ -722,7 +764,7 @@ class Engine:
         def out_proj_back(plan, dS, a, wname):
             """dW, db of an attention out_proj and d(attention output) -> t2."""
             if F_OUT:
-                dlin(plan, dS, a, wname, R, H, H)
+                dlin(plan, dS, a, wname, R, H, H, defer=True)        # leaves with the next LayerNorm-fed linear's weight gradient
                 K.rowgemm(dS, prep["v"][wname]["WpT"], t2, R, H, H, plan=plan)
             else:
                 dlin(plan, dS, a, wname, R, H, H, dX=t2)
@@ -734,8 +776,10 @@ class Engine:
                                  lddq=3 * H, lddkv=3 * H, dkoff=H, dvoff=2 * H), plan=plan)
             if F_QKV:
                 dlin_ln(plan, dqkv, tag + "/ln1", p + ".attn.qkv", p + ".ln1", 3 * H)
+                flush_deferred(plan)
                 dx_ln(plan, dqkv, 3 * H, tag + "/ln1", p + ".attn.qkv", dS, dS)
             else:
+                flush_deferred(plan)
                 dlin(plan, dqkv, self.b[tag + "/h1"], p + ".attn.qkv", R, 3 * H, H, dX=dh_)
                 ln_b(plan, dh_, X_in, p + ".ln1", tag + "/ln1", dS, dS)
 
@@ -750,10 +794,12 @@ class Engine:
                                  d_o=t2, dq=dqc, dkv=dkvc, lddq=H, lddkv=2 * H, dkoff=0, dvoff=H), plan=cur)
             if F_LNL:
                 dlin_ln(cur, dqc, tag + "/qn", p + ".cross_attn.query", p + ".query_norm", H)
+                flush_deferred(cur)
                 dx_ln(cur, dqc, H, tag + "/qn", p + ".cross_attn.query", dY, dY)
                 dlin_ln(cur, dkvc, tag + "/cn", p + ".cross_attn.kv", p + ".context_norm", 2 * H)
                 dx_ln(cur, dkvc, 2 * H, tag + "/cn", p + ".cross_attn.kv", None if first_ctx else dctx, dctx)
             else:
+                flush_deferred(cur)
                 dlin(cur, dqc, self.b[tag + "/hq"], p + ".cross_attn.query", R, H, H, dX=dh_)
                 ln_b(cur, dh_, self.b[tag + "/xa"], p + ".query_norm", tag + "/qn", dY, dY)
                 dlin(cur, dkvc, self.b[tag + "/hc"], p + ".cross_attn.kv", R, 2 * H, H, dX=dh_)

@@ -48,9 +48,9 @@ def dropout(state, site, p):
     return L.Dropout(state.data_ptr(), site, float(p))
 
 
-def gemm(A, B, Cout, M, N, K, *, lda, ldb, ldc, a_kcontig=1, b_kcontig=1, bias=None, pre_out=None, act=0,
-         act_scale=1.0, gradmul_pre=None, drop=None, residual=None, ldr=0, splits=1, kchunk=0, slab_stride=0,
-         dtype=None, c_f32=0, colsum=None, plan=None):
+def gemm_desc(A, B, Cout, M, N, K, *, lda, ldb, ldc, a_kcontig=1, b_kcontig=1, bias=None, pre_out=None, act=0,
+              act_scale=1.0, gradmul_pre=None, drop=None, residual=None, ldr=0, splits=1, kchunk=0, slab_stride=0,
+              dtype=None, c_f32=0, colsum=None):
     d = L.GemmDesc()
     d.dtype = dt(A) if dtype is None else dtype
     d.c_f32 = c_f32
@@ -62,7 +62,17 @@ def gemm(A, B, Cout, M, N, K, *, lda, ldb, ldc, a_kcontig=1, b_kcontig=1, bias=N
     d.drop = drop if drop is not None else L.NO_DROP
     d.residual, d.ldr = P(residual), ldr
     d.colsum = colsum if isinstance(colsum, int) else P(colsum)
+    return d
+
+
+def gemm(A, B, Cout, M, N, K, *, plan=None, **kw):
+    d = gemm_desc(A, B, Cout, M, N, K, **kw)
     _emit(plan, L.lib().mmfm_gemm, (C.byref(d),), keep=(d,))
+
+
+def gemm_pair(da, db, plan=None):
+    """Two independent products (descriptors from gemm_desc) through mmfm_gemm_pair: two streaming weight-gradient launches become one."""
+    _emit(plan, L.lib().mmfm_gemm_pair, (C.byref(da), C.byref(db)), keep=(da, db))
 
 
 def reduce_slabs(dst, src, n, nslabs, stride, accumulate=False, plan=None):

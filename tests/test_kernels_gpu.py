@@ -954,3 +954,41 @@ def test_reduce_slabs_multi_matches_single_reductions(ops):
     ops.reduce_slabs_multi(items, "cuda")
     for (dst, *_), ref in zip(items, refs):
         close(dst, ref, rtol=1e-5, atol=1e-5, msg="reduce_slabs_multi")
+
+
+def test_gemm_pair_two_weight_gradients_in_one_launch(ops):
+    """mmfm_gemm_pair: the MLP's two weight gradients (512x256 and 256x512 over R rows, column sums riding along) from ONE launch of the
+    streaming kernel, each on its share of the CUs, against the same two products issued separately and against fp64."""
+    R = 51200
+    dy1, x1 = bf(rnd(R, 512, seed=31)), bf(rnd(R, 256, seed=32))
+    dy2, x2 = bf(rnd(R, 256, seed=33)), bf(rnd(R, 512, seed=34))
+
+    def run(pair):
+        outs = []
+        descs = []
+        for dy, x, S in ((dy1, x1, 32), (dy2, x2, 32)):
+            N, K = dy.shape[1], x.shape[1]
+            kchunk = (-(-R // S) + 63) // 64 * 64
+            S2 = -(-R // kchunk)
+            stride = (N * K + N + 7) // 8 * 8
+            slabs = torch.full((S2, stride), float("nan"), device="cuda")
+            kw = dict(lda=N, ldb=K, ldc=K, a_kcontig=0, b_kcontig=0, splits=S2, kchunk=kchunk, slab_stride=stride, c_f32=1, colsum=slabs.data_ptr() + 4 * N * K)
+            descs.append((ops.gemm_desc(dy, x, slabs, N, K, R, **kw), slabs, N, K, S2, stride))
+        if pair:
+            ops.gemm_pair(descs[0][0], descs[1][0])
+        else:
+            from multi_modal_foundation_model_amd import _lib as L
+            import ctypes as C
+            for d in descs:
+                assert L.lib().mmfm_gemm(C.byref(d[0]), None) == 0
+        for _, slabs, N, K, S2, stride in descs:
+            out = torch.empty(N * K + N, device="cuda")
+            ops.reduce_slabs(out, slabs, N * K + N, S2, stride)
+            outs.append(out)
+        return outs
+    a, b = run(True), run(False)
+    for o, r, (dy, x) in zip(a, b, ((dy1, x1), (dy2, x2))):
+        assert torch.equal(o, r)                    # same kernel, same split: bit-identical to the separate launches
+        N, K = dy.shape[1], x.shape[1]
+        close_bf16(o[:N * K].view(N, K), dy.double().T @ x.double(), "paired dW", tol=2e-3)
+        close(o[N * K:], dy.double().sum(0).float(), rtol=1e-5, atol=1e-4 * math.sqrt(R), msg="paired bias grad")
