@@ -87,6 +87,10 @@ def kernel_profile(engine, plan, reps=3):
             d = keep[0]
             flops = 2.0 * d.M * d.N * d.K
             sub = "x.W^T" if (d.a_kcontig and d.b_kcontig) else ("dY.W" if d.a_kcontig else "dY^T.X")
+        elif name == "mmfm_gemm_pair":          # two weight gradients in one launch: one launch of the GEMM family
+            name = "mmfm_gemm"
+            flops = sum(2.0 * d.M * d.N * d.K for d in keep[:2])
+            sub = "dY^T.X"
         elif name == "mmfm_rowgemm":
             d = keep[0]
             flops = 2.0 * d.R * d.N * d.K

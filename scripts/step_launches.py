@@ -66,6 +66,11 @@ for i, (fn, args, keep) in enumerate(entries):
         by = 2.0 * (d.M * d.K + d.K * d.N) + esz * d.M * d.N * max(1, d.splits) + (2.0 * d.M * d.N if d.pre_out else 0) \
             + (2.0 * d.M * d.N if d.residual else 0) + (2.0 * d.M * d.N if d.gradmul_pre else 0)
         fl = 2.0 * d.M * d.N * d.K
+    elif name == "mmfm_gemm_pair":
+        da, db = keep[0], keep[1]
+        key = f"gemm pair dY^T.X {da.M}x{da.N} s{da.splits} + {db.M}x{db.N} s{db.splits} K={da.K}"
+        by = sum(2.0 * (d.M * d.K + d.K * d.N) + 4.0 * d.M * d.N * max(1, d.splits) for d in (da, db))
+        fl = sum(2.0 * d.M * d.N * d.K for d in (da, db))
     elif name == "mmfm_rowgemm":
         d = keep[0]
         key = f"rowgemm R={d.R} N={d.N} K={d.K}" + (" LN" if d.ln else "") + (" +res" if d.residual else "") + (" LNbwd" if d.ln_bwd else "")
