@@ -101,7 +101,9 @@ __global__ __launch_bounds__(NWV * 64, (KP == 1 ? 2 : 1)) void rowgemm_kernel(co
 // y = dres + rstd * (v - mean(v) - x_hat * mean(v * x_hat))
 template <int KP>
 __global__ __launch_bounds__(NT) void rowgemm_lnbwd_kernel(const mmfm_rowgemm_desc d) {
-    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + NW * STG_BYTES];
+    // + a 16 KB per-wave stash of the pass's x_hat rows (as in the MLP backward): the statistics loop fetches them once, the output
+    // loop reads them from LDS instead of putting a second dependent round trip per line pair into every pass
+    __shared__ __attribute__((aligned(16))) char smem[LDS_BYTES + NW * STG_BYTES + NW * 4 * STG_BYTES];
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
     constexpr int cpp = 8 * KP;
     const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
@@ -117,6 +119,7 @@ __global__ __launch_bounds__(NT) void rowgemm_lnbwd_kernel(const mmfm_rowgemm_de
         return c;
     };
     char* stg = smem + LDS_BYTES + wave * STG_BYTES;
+    char* xstash = smem + LDS_BYTES + NW * STG_BYTES + wave * 4 * STG_BYTES;
     const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), RES = gbuf(d.residual, d.R * d.ldr * 2);
     const GBuf XH = gbuf(d.bwd_xhat, d.R * 512), RS = gbuf(d.bwd_rstd, d.R * 4);
     const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2, ldrb = d.ldr * 2;
@@ -144,25 +147,26 @@ __global__ __launch_bounds__(NT) void rowgemm_lnbwd_kernel(const mmfm_rowgemm_de
                     acc[2 * tp + j] = mma16(slot, x + 16 * p, acc[2 * tp + j], m, h);
                 }
             }
-            stage_lines(stg, xl, lane);
+            stage_lines(xstash + tp * STG_BYTES, xl, lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const f32x16 xt = unstage_tile(stg, j, m, h);
+                const f32x16 xt = unstage_tile(xstash + tp * STG_BYTES, j, m, h);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) { s1 += acc[2 * tp + j][i]; s2 = fmaf(acc[2 * tp + j][i], xt[i], s2); }
             }
         }
         s1 = xhalf(s1) * (1.f / 256.f);
         s2 = xhalf(s2) * (1.f / 256.f);
+        Lines rl4[4];                                   // the residual-gradient lines, requested together (the operand registers are dead here)
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) rl4[tp] = fetch_lines(RES, wrow0, ldrb, 128u * tp, lane);
 #pragma unroll
         for (int tp = 0; tp < 4; ++tp) {
-            const Lines xl = fetch_lines(XH, wrow0, 512u, 128u * tp, lane);
-            const Lines rl = fetch_lines(RES, wrow0, ldrb, 128u * tp, lane);
-            stage_lines(stg, xl, lane);
+            const Lines& rl = rl4[tp];
             f32x16 o[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const f32x16 xt = unstage_tile(stg, j, m, h);
+                const f32x16 xt = unstage_tile(xstash + tp * STG_BYTES, j, m, h);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) o[j][i] = rs * (acc[2 * tp + j][i] - s1 - xt[i] * s2);
             }
