@@ -91,18 +91,26 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
         const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
         const uint32_t row = wrow0 + m;
         opnd x[16], t1[16];
-        {   // x_hat: fetched as whole lines into the stash (which doubles as the transposition area for the operand reads) and kept
-            Lines L[4];
+        {   // x_hat: fetched as whole lines into the stash (which doubles as the transposition area for the operand reads) and kept;
+            // the dy rows are requested in the same breath (one round trip for both row blocks)
+            Lines L[4], Ld[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) L[q] = fetch_lines(XH, wrow0, 512u, 128u * q, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ld[q] = fetch_lines(DY, wrow0, lddyb, 128u * q, lane);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 stage_lines(xstash + q * STG_BYTES, L[q], lane);
 #pragma unroll
                 for (int s4 = 0; s4 < 4; ++s4) x[4 * q + s4] = unstage_opnd(xstash + q * STG_BYTES, s4, m, h);
             }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                stage_lines(stg, Ld[q], lane);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) t1[4 * q + s4] = unstage_opnd(stg, s4, m, h);
+            }
         }
-        load_rows_lines<4>(stg, t1, DY, wrow0, lddyb, lane, m, h);
         const float rs = ld4f(RS, row * 4u);
         if (dr.on()) {                                      // dropout'(dy): counter row*256 + k, k = 16s + 8h + j
 #pragma unroll
@@ -344,11 +352,13 @@ __global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
 #undef F8_READ
             STAMP(5);
         }
+        Lines xl2[2];                                                           // both residual line pairs requested together
+#pragma unroll
+        for (int q = 0; q < 2; ++q) xl2[q] = fetch_lines(X, wrow0, ldxb, 128u * (2 * role + q), lane);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int lp = 2 * role + q;                                        // line pair = output tiles 2*lp, 2*lp+1
-            const Lines xl = fetch_lines(X, wrow0, ldxb, 128u * lp, lane);
-            stage_lines(stg, xl, lane);
+            stage_lines(stg, xl2[q], lane);
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int t2 = 2 * lp + j;
