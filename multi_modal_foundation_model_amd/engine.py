@@ -446,8 +446,11 @@ class Engine:
         pend: list = []
         slabm_off = [0]
         if batch_red:
+            # regions are handed out per backward segment and reused by the next one (close_segment resets the offset behind the segment's
+            # reduction): the largest segment's parameters bound the need, not the whole model's
             s_max = max(1, min(R // 256, 15))
-            slabm = buf("ws/slabm", (s_max * (self.layout.n + 128 * 64),), f32)
+            seg_max = max(e - s0 for _, s0, e in self.layout.segments)
+            slabm = buf("ws/slabm", (s_max * (seg_max + 128 * 64),), f32)
 
         def slab_region(S, stride):
             o = slabm_off[0]
@@ -726,6 +729,7 @@ class Engine:
             if pend:                          # the segment's weight-gradient slabs, all in one launch, before its DDP hook fires
                 K.reduce_slabs_multi(list(pend), self.device, plan=cur)
                 pend.clear()
+            slabm_off[0] = 0                  # the reduction has consumed the regions (stream order): the next segment reuses them
             bwd.append((name, cur))
             cur = []
 
