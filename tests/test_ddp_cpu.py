@@ -127,3 +127,30 @@ def test_accelerator_single_process_is_passthrough():
     m = torch.nn.Linear(2, 2)
     assert acc.prepare(m) is m or isinstance(acc.prepare(m), torch.nn.Linear)
     assert acc.is_main_process
+
+
+def _save_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "multi_modal_foundation_model_amd", "src"))
+    from trainer.base import MultiModalTrainer
+    t = MultiModalTrainer.__new__(MultiModalTrainer)              # the checkpoint methods only: no model build, no GPU
+    torch.manual_seed(100 + rank)                                  # per-rank RNG streams, as under data parallelism
+    t.model = torch.nn.Linear(3, 2)
+    t.optimizer = torch.optim.AdamW(t.model.parameters(), lr=1e-3)
+    t.lr_scheduler, t.log_dir, t.session_active_neurons = None, out_dir, []
+    t.save_model(name="last", epoch=3)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_checkpoint_writes_are_rank_guarded_gloo(tmp_path):
+    """Under data parallelism the module pickle is written by rank 0 only (replicas are identical; concurrent writers tear the file) and
+    every rank keeps its own training state (its RNG streams differ): trainer/base.py save_model / save_train_state."""
+    world, port = 2, _free_port()
+    mp.spawn(_save_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    files = sorted(os.listdir(tmp_path))
+    assert files == ["model_last.pt", "train_state_last_rank0.pt", "train_state_last_rank1.pt"], files
+    st = [torch.load(tmp_path / f"train_state_last_rank{r}.pt", weights_only=False) for r in range(world)]
+    assert st[0]["epoch"] == st[1]["epoch"] == 3
+    assert not torch.equal(st[0]["torch_rng"], st[1]["torch_rng"])           # each rank's own stream
