@@ -274,6 +274,11 @@ int mmfm_gemm_big_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
     static const int kmin = [] { const char* e = getenv("MMFM_GEMM_BIG_KMIN"); return e ? atoi(e) : 512; }();
     if (!on || d.dtype != MMFM_BF16 || d.c_f32 || d.splits > 1 || !d.a_kcontig || !d.b_kcontig || d.colsum) return -1000;
     if (d.K % BK || d.K < kmin || d.N < 128 || d.M < 1024 || d.N % 8) return -1000;
+    // too few 256-wide tiles to occupy the chip (the reference's batch of 16: M = 3,200 rows x N = 256 = 13 tiles, 23-34 us against ~15 us
+    // for the 50 tiles of the 128-tile kernel)
+    // (MMFM_GEMM_BIG_MIN_TILES is read per call: the kernel's own test lowers it for its small shapes)
+    const char* mt = getenv("MMFM_GEMM_BIG_MIN_TILES");
+    if (cdiv(d.M, TB) * cdiv(d.N, TB) < (mt ? atoi(mt) : 96)) return -1000;
     auto al16 = [](const void* p) { return p == nullptr || (uintptr_t)p % 16 == 0; };
     if (d.lda % 8 || d.ldb % 8 || d.ldc % 8 || (d.residual && d.ldr % 8) || !al16(d.A) || !al16(d.B) || !al16(d.C) || !al16(d.pre_out) ||
         !al16(d.gradmul_pre) || !al16(d.residual) || !al16(d.bias))
