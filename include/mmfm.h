@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MMFM_VERSION 200
+#define MMFM_VERSION 300
 #define MMFM_F32 0
 #define MMFM_BF16 1
 
