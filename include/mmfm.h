@@ -283,7 +283,10 @@ typedef struct {
                                 0, 2, 1, 3 ("unit-permuted": the order in which an MFMA accumulator tile, used as the next product's
                                 operand, holds its k index - rowchain.h).  LDS-DMA cannot permute on the way in, so the kernels that
                                 multiply such operands read these copies: mmfm_mlp_fwd's w_down */
-    void* WpTP;              /* bf16 [K][N] or NULL: WpT unit-permuted along N: mmfm_mlp_bwd's w_up_t */
+    void* WpTP;              /* bf16 [K][N] or NULL: WpT unit-permuted along N: mmfm_mlp_bwd's w_up_t.
+                                The permutation acts on aligned groups of 16 elements: WpP requires K % 16 == 0 and WpTP requires
+                                N % 16 == 0 (a ragged last group has no permuted position inside its row: the kernel leaves those
+                                elements unwritten rather than spill into the next row) */
 } mmfm_prep_entry;
 int mmfm_prep_weights(const mmfm_prep_entry* entries, int n_entries, int total_tiles, mmfm_stream stream);
 

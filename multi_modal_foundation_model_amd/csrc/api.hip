@@ -1,6 +1,8 @@
 // Library-level entry points: version, thread-local error text, device check, RNG state.
 #include "common.h"
 #include <string.h>
+#include <mutex>
+#include <unordered_map>
 
 static thread_local char g_err[512] = "";
 
@@ -10,6 +12,21 @@ int mmfm_set_error(int code, const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code == 0 ? -1 : code;
+}
+
+int mmfm_lds_opt_in(const void* kern, size_t bytes, const char* what) {
+    static std::mutex mu;
+    static std::unordered_map<uint64_t, bool> done;
+    if (bytes <= 65536) return 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t key = (uint64_t)(uintptr_t)kern ^ ((uint64_t)(dev + 1) << 56);
+    std::lock_guard<std::mutex> g(mu);
+    if (done.count(key)) return 0;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return mmfm_set_error((int)e, "%s: hipFuncSetAttribute(%zu B LDS): %s", what, bytes, hipGetErrorString(e));
+    done[key] = true;
+    return 0;
 }
 
 extern "C" int mmfm_version(void) { return MMFM_VERSION; }

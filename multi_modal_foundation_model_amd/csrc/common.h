@@ -28,6 +28,10 @@ int mmfm_set_error(int code, const char* fmt, ...);
             return mmfm_set_error((int)e__, "%s: launch failed: %s", name, hipGetErrorString(e__)); \
     } while (0)
 
+// Dynamic-LDS opt-in above 64 KB (hipFuncAttributeMaxDynamicSharedMemorySize), remembered per (device, kernel): the attribute belongs
+// to the pair, so a process that drives several GPUs opts in on each (api.hip).  `what` names the entry point in the error text.
+int mmfm_lds_opt_in(const void* kern, size_t bytes, const char* what);
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ------------------------------------------------------------------ bf16 <-> f32

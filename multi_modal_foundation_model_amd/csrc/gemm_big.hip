@@ -284,12 +284,7 @@ int mmfm_gemm_big_launch(const mmfm_gemm_desc* dp, hipStream_t st) {
         !al16(d.gradmul_pre) || !al16(d.residual) || !al16(d.bias))
         return -1000;
     if ((int64_t)d.M * std::max(d.ldc, d.ldr) * 2 >= (int64_t)1 << 31) return -1000;        // 32-bit buffer offsets of the epilogue
-    static bool opted = false;
-    if (!opted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ALL);
-        if (e != hipSuccess) return mmfm_set_error((int)e, "mmfm_gemm(bf16, 256 tile): hipFuncSetAttribute(%d B LDS): %s", LDS_ALL, hipGetErrorString(e));
-        opted = true;
-    }
+    if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(gemm_big_kernel), LDS_ALL, "mmfm_gemm(bf16, 256 tile)")) return rc;
     static const int nt_env = [] { const char* e = getenv("MMFM_GEMM_NT"); return e ? atoi(e) : 3; }();
     BigArgs a;
     a.d = d;

@@ -254,12 +254,7 @@ DwArgs make_args(const mmfm_gemm_desc& d) {
 template <int TN, int BK>
 int launch(const mmfm_gemm_desc& d, const mmfm_gemm_desc* d2, hipStream_t st) {
     typedef Geo<TN, BK> G;
-    static bool opted = false;
-    if (!opted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_dw_kernel<TN, BK>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        if (e != hipSuccess) return mmfm_set_error((int)e, "mmfm_gemm(bf16, dW stream): hipFuncSetAttribute(%d B LDS): %s", G::LDS, hipGetErrorString(e));
-        opted = true;
-    }
+    if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(gemm_dw_kernel<TN, BK>), G::LDS, "mmfm_gemm(bf16, dW stream)")) return rc;
     DwPair p;
     p.a = make_args<TN>(d);
     p.b = p.a;

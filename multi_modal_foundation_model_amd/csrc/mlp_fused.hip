@@ -462,12 +462,7 @@ extern "C" int mmfm_mlp_fwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
     {
         constexpr int LDS_A = RINGA_SLOTS * CHUNK2 + 8 * STG_BYTES + 4 * 4096 + 768 * 4;
-        static bool opted = false;
-        if (!opted) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_fwd8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_A);
-            if (e != hipSuccess) return mmfm_set_error((int)e, "mmfm_mlp_fwd: hipFuncSetAttribute(%d B LDS): %s", LDS_A, hipGetErrorString(e));
-            opted = true;
-        }
+        if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(mlp_fwd8_kernel), LDS_A, "mmfm_mlp_fwd")) return rc;
         hipLaunchKernelGGL(mlp_fwd8_kernel, dim3(grid_for(d.R, per_cu, 4)), dim3(NT8), LDS_A, (hipStream_t)stream, d);
     }
     MMFM_LAUNCH_CHECK("mmfm_mlp_fwd");
@@ -479,12 +474,7 @@ extern "C" int mmfm_mlp_bwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     if (int rc = check(d, true)) return rc;
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
     constexpr int LDS_B = RINGA_SLOTS * CHUNK + 2 * NW * STG_BYTES + 512 * 4 + NW * 4 * STG_BYTES;
-    static bool opted = false;
-    if (!opted) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_B);
-        if (e != hipSuccess) return mmfm_set_error((int)e, "mmfm_mlp_bwd: hipFuncSetAttribute(%d B LDS): %s", LDS_B, hipGetErrorString(e));
-        opted = true;
-    }
+    if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(mlp_bwd_kernel), LDS_B, "mmfm_mlp_bwd")) return rc;
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), LDS_B, (hipStream_t)stream, d);
     MMFM_LAUNCH_CHECK("mmfm_mlp_bwd");
     return 0;

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const mmfm_prep_entry
             const float w = v * g;
             dot[j] = fmaf(v, bt, dot[j]);
             if (Wp && n < en.N && k < en.K) Wp[(size_t)n * en.K + k] = f2bf(w);
-            if (WpP && n < en.N && k < en.K) WpP[(size_t)n * en.K + perm(k)] = f2bf(w);
+            if (WpP && n < en.N && k < en.K && perm(k) < en.K) WpP[(size_t)n * en.K + perm(k)] = f2bf(w);    // K % 16 == 0 (mmfm.h)
             tile[ty + 8 * j][tx] = w;
         }
         __syncthreads();
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const mmfm_prep_entry
                 const int kk = k0 + ty + 8 * j, n = n0 + tx;
                 if (kk < en.K && n < en.N) {
                     if (WpT) WpT[(size_t)kk * en.N + n] = f2bf(tile[tx][ty + 8 * j]);
-                    if (WpTP) WpTP[(size_t)kk * en.N + perm(n)] = f2bf(tile[tx][ty + 8 * j]);
+                    if (WpTP && perm(n) < en.N) WpTP[(size_t)kk * en.N + perm(n)] = f2bf(tile[tx][ty + 8 * j]);   // N % 16 == 0 (mmfm.h)
                 }
             }
         }

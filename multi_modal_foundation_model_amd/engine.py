@@ -432,14 +432,21 @@ class Engine:
         # ---- workspaces
         max_slab = 1
         for _, n in c.mods:
-            for (mm, nn) in ((n * c.mult, n), (H, n * c.mult), (n, H)):
-                S, _ = self._dw_split(mm, nn, BT)
+            # the same arguments the launches below pass (the token embedding reads its input rows padded to 16 B: ldn selects the
+            # streaming kernel and with it another split count)
+            for (mm, nn, ldn) in ((n * c.mult, n, _align(n, 8)), (H, n * c.mult, None), (n, H, None)):
+                S, _ = self._dw_split(mm, nn, BT, ldn=ldn)
                 max_slab = max(max_slab, S * _align(mm * nn + mm))
         for (mm, nn) in ((3 * H, H), (H, H), (2 * H, H), (I, H), (H, I)):
             S, _ = self._dw_split(mm, nn, R)
             max_slab = max(max_slab, S * _align(mm * nn + mm))
         slab = buf("ws/slab", (max_slab,), f32)
         slab2 = buf("ws/slab2", (max_slab,), f32)          # a deferred weight-gradient GEMM's slabs, paired with the next one (mmfm_gemm_pair)
+
+        def slab_fits(t, S, stride, what):
+            if S * stride > t.numel():
+                raise RuntimeError(f"engine: {what}: {S} slabs x {stride} floats exceed the {t.numel()}-float slab workspace")
+            return t
         # launch-bound regime (R <= 8192, the reference's batch of 16): every dW GEMM keeps its own slab region and ONE
         # mmfm_reduce_slabs_multi per backward segment sums them all (66 reductions of ~7 us each otherwise)
         batch_red = R <= 8192 and os.environ.get("MMFM_BATCH_REDUCE", "1") != "0"
@@ -513,7 +520,7 @@ class Engine:
                        colsum=gb if fused else None, plan=plan)
             elif adjacent:
                 stride = _align(N * Kd + N)
-                sl = slab_region(S, stride) if batch_red else slab
+                sl = slab_region(S, stride) if batch_red else slab_fits(slab, S, stride, wname)
                 K.gemm(dY, X, sl, N, Kd, Mr, lda=N, ldb=ldx, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
                        slab_stride=stride, dtype=code, c_f32=1, colsum=sl.data_ptr() + 4 * N * Kd, plan=plan)
                 if batch_red:
@@ -521,7 +528,7 @@ class Engine:
                 else:
                     K.reduce_slabs(gw, sl, N * Kd + N, S, stride, plan=plan)
             else:
-                sl = slab_region(S, N * Kd) if batch_red else slab
+                sl = slab_region(S, N * Kd) if batch_red else slab_fits(slab, S, N * Kd, wname)
                 K.gemm(dY, X, sl, N, Kd, Mr, lda=N, ldb=ldx, ldc=Kd, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
                        slab_stride=N * Kd, dtype=code, c_f32=1, plan=plan)
                 if batch_red:
@@ -591,6 +598,7 @@ class Engine:
                 Na, Ka = a["N"], a["Kd"]
                 Sa, kca, Sb, kcb = pair_splits(Na, Ka, N, H, R)
                 stra, strb = _align(Na * Ka + Na), _align(N * H + N)
+                slab_fits(slab2, Sa, stra, a["wname"]); slab_fits(slab, Sb, strb, wname)
                 da = K.gemm_desc(a["dY"], a["X"], slab2, Na, Ka, R, lda=Na, ldb=Ka, ldc=Ka, a_kcontig=0, b_kcontig=0, splits=Sa, kchunk=kca,
                                  slab_stride=stra, dtype=code, c_f32=1, colsum=slab2.data_ptr() + 4 * Na * Ka)
                 db_ = K.gemm_desc(dYt, xh, slab, N, H, R, lda=N, ldb=H, ldc=H, a_kcontig=0, b_kcontig=0, splits=Sb, kchunk=kcb,
@@ -603,6 +611,7 @@ class Engine:
                        colsum=gdb.data_ptr() + 4 * N * H, plan=plan)
             else:
                 stride = _align(N * H + N)
+                slab_fits(slab, S, stride, wname)
                 K.gemm(dYt, xh, slab, N, H, R, lda=N, ldb=H, ldc=H, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
                        slab_stride=stride, dtype=code, c_f32=1, colsum=slab.data_ptr() + 4 * N * H, plan=plan)
                 K.reduce_slabs(gdb, slab, N * H + N, S, stride, plan=plan)

@@ -190,6 +190,10 @@ def prep_table(entries, device):
     tile0 = 0
     for i, e in enumerate(entries):
         N, Kd = e["W"].shape
+        if e.get("WpP") is not None and Kd % 16:
+            raise ValueError(f"prep_table: entry {i}: WpP (unit-permuted along K) needs K % 16 == 0, got K = {Kd} (include/mmfm.h)")
+        if e.get("WpTP") is not None and N % 16:
+            raise ValueError(f"prep_table: entry {i}: WpTP (unit-permuted along N) needs N % 16 == 0, got N = {N} (include/mmfm.h)")
         a = arr[i]
         a.W, a.gamma, a.beta, a.bias = P(e["W"]), P(e.get("gamma")), P(e.get("beta")), P(e.get("bias"))
         a.Wp, a.WpT, a.bp = P(e.get("Wp")), P(e.get("WpT")), P(e.get("bp"))

@@ -64,22 +64,27 @@ class Masker(nn.Module):
         self.target_regions = config.target_regions
         self.n_mask_regions = config.n_mask_regions
         self.causal_zero = config.causal_zero
-        # Throughput switch (NOT the default): in the `embd` masking path the caller discards the
-        # corrupted spikes, so only the token-level draw matters.  Skipping the three full-size draws
-        # changes the generator stream (masks stay identically distributed, not bit-identical).
+        # Throughput switch of ONE training run, set by the trainer (trainer/base.py: it IS the trainer's default for
+        # mask_type 'embd'; `training.exact_masker_stream: true` / MMFM_EXACT_MASKER=1 keeps it off): in the `embd` masking
+        # path the caller discards the corrupted spikes, so only the token-level draw matters.  Skipping the three full-size
+        # draws shortens the walk through the CPU generator: masks stay identically distributed but, from the second masker
+        # call on, are NOT the reference's bit for bit.  It is honoured only by callers that discard the spikes (they pass it
+        # per call, mm.py) and it is never pickled: a checkpoint always starts on the reference's stream.
         self.token_mask_only = False
         self._ring = _PinnedRing()
 
     def __getstate__(self):                    # checkpoints pickle the whole model: drop pinned buffers / events
         state = self.__dict__.copy()
         state["_ring"] = None
+        state["token_mask_only"] = False       # a run's throughput switch must not leak into model_best.pt / model_last.pt
         return state
 
     @staticmethod
     def _no_mask(spikes):
         return spikes, torch.zeros_like(spikes).to(torch.int64)
 
-    def forward(self, spikes, neuron_regions=None):
+    def forward(self, spikes, neuron_regions=None, token_mask_only=False):
+        """`token_mask_only=True` (callers that discard the returned spikes only): skip the zero / random corruption draws."""
         inactive = (not self.training and not self.force_active) or self.target_regions is None \
             or self.mask_regions is None or self.ratio == 0
         if inactive:
@@ -151,7 +156,7 @@ class Masker(nn.Module):
         else:
             mask = drawn.bool()
 
-        if not self.token_mask_only:
+        if not token_mask_only:
             zero_idx = torch.bernoulli(torch.full((B, T, N), float(self.zero_ratio))).to(dev).bool() & mask
             spikes[zero_idx] = 0
             rand_idx = torch.bernoulli(torch.full((B, T, N), float(self.random_ratio))).to(dev).bool() & mask & ~zero_idx

@@ -152,7 +152,8 @@ class MultiModal(nn.Module):
                 raise UnboundLocalError("local variable 'mask' referenced before assignment "
                                         "(upstream behaviour of mask_type='input', mm.py:256-272)")
             if d['eval_mask'] is None:
-                _, mask = self.masker(d['inputs'].clone(), regions)
+                # the corrupted spikes are discarded here (mm.py:267), so the trainer's token-mask-only switch applies
+                _, mask = self.masker(d['inputs'].clone(), regions, token_mask_only=bool(self.masker.token_mask_only))
             else:
                 mask = d['eval_mask']
             mask = mask[:, :, 0] & d['inputs_attn_mask']

@@ -107,8 +107,14 @@ class MultiModalTrainer():
         masker = getattr(self.model, "masker", None)
         exact = bool(self.config.training.get("exact_masker_stream", False)) if hasattr(self.config.training, "get") else False
         exact = exact or os.environ.get("MMFM_EXACT_MASKER", "0") == "1"
-        if masker is not None and hasattr(masker, "token_mask_only") and self.config.training.mask_type == "embd" and not exact:
-            masker.token_mask_only = True
+        if masker is not None and hasattr(masker, "token_mask_only"):
+            # a per-run switch: set on every construction (never inherited from a loaded checkpoint, Masker.__getstate__ drops it)
+            masker.token_mask_only = bool(self.config.training.mask_type == "embd" and not exact)
+            if self._rank_world()[0] == 0:
+                print("(train) masker stream: " + (
+                    "token-mask-only (same mask distribution; from the second masker call on NOT the reference's generator stream - "
+                    "set training.exact_masker_stream: true or MMFM_EXACT_MASKER=1 for bit-exact masks)" if masker.token_mask_only
+                    else "reference-exact (every [B,T,N] corruption draw of models/masker.py is taken)"))
         # host-side constants of the batch -> mod_dict translation, built once instead of every step: the
         # modality-index scalars (a pageable H2D copy each = a stream drain per call) and the [B, N] region array
         self._mod_index_cache = {}
@@ -178,7 +184,10 @@ class MultiModalTrainer():
             print(f"epoch: {epoch} train loss: {train_res['train_loss']}")
             key = f'eval_trial_avg_{self.metric}'
             if eval_res:
-                if eval_res[key] > best_metric:
+                # every rank evaluates its own shard, so "improved" can differ between ranks while save_model is collective
+                # (rank-guarded write + barrier): rank 0 decides for all, or one rank would sit in the barrier while the
+                # others wait for it in the next step's gradient all-reduce
+                if self._rank0_decides(bool(eval_res[key] > best_metric)):
                     best_eval_loss, best_metric = eval_res['eval_loss'], eval_res[key]
                     print(f"epoch: {epoch} best eval loss: {best_eval_loss} trial avg {self.metric}: {best_metric}")
                     self.save_model(name="best", epoch=epoch)
@@ -283,6 +292,16 @@ class MultiModalTrainer():
         self.save_train_state(name=name, epoch=epoch)
         if world > 1:
             torch.distributed.barrier()
+
+    def _rank0_decides(self, flag):
+        """Rank 0's boolean on every rank (one tiny broadcast; a no-op without data parallelism)."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return bool(flag)
+        dev = self.accelerator.device if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+        dist.broadcast(t, src=0)
+        return bool(int(t.item()))
 
     @staticmethod
     def _rank_world():

@@ -154,3 +154,48 @@ def test_checkpoint_writes_are_rank_guarded_gloo(tmp_path):
     st = [torch.load(tmp_path / f"train_state_last_rank{r}.pt", weights_only=False) for r in range(world)]
     assert st[0]["epoch"] == st[1]["epoch"] == 3
     assert not torch.equal(st[0]["torch_rng"], st[1]["torch_rng"])           # each rank's own stream
+
+
+def _best_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.join(ROOT, "multi_modal_foundation_model_amd", "src"))
+    from trainer.base import MultiModalTrainer
+    from utils.config_utils import DictConfig
+
+    class Acc:
+        device = torch.device("cpu")
+    t = MultiModalTrainer.__new__(MultiModalTrainer)              # the epoch loop with stand-in epochs: no model build, no GPU
+    t.model = torch.nn.Linear(3, 2)
+    t.optimizer = torch.optim.AdamW(t.model.parameters(), lr=1e-3)
+    t.lr_scheduler, t.log_dir, t.session_active_neurons, t.accelerator = None, out_dir, [], Acc()
+    t.config = DictConfig(dict(training=dict(num_epochs=3, save_plot_every_n_epochs=1000)))
+    t.metric, t.use_wandb, t.modal_filter = "r2", False, {"output": []}
+    # rank-local evaluation shards: the metric improves on rank 1 only in epoch 1 and on rank 0 only in epoch 2
+    metric = {0: [0.1, 0.1, 0.3], 1: [0.1, 0.2, 0.2]}[rank]
+    t.train_epoch = lambda epoch: {"train_loss": 0.0}
+    state = {"e": -1}
+
+    def eval_epoch():
+        state["e"] += 1
+        return {"eval_loss": 1.0, "eval_trial_avg_r2": metric[state["e"]], "eval_gt": {}, "eval_preds": {}}
+    t.eval_epoch = eval_epoch
+    saved = []
+    real_save = t.save_model
+    t.save_model = lambda name="last", epoch=0: (saved.append((name, epoch)), real_save(name=name, epoch=epoch))[1]
+    t.train()                                                      # deadlocks (mp.spawn join never returns) if ranks disagree on "best"
+    with open(os.path.join(out_dir, f"saved{rank}.txt"), "w") as f:
+        f.write(repr(saved))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_best_checkpoint_decision_is_collective_gloo(tmp_path):
+    """`save_model` ends in a barrier, and `train()` calls it for 'best' from a comparison of RANK-LOCAL
+    evaluation metrics.  Rank 0's comparison decides for every rank; with per-rank decisions one rank would wait in the barrier
+    while the other went on to the next epoch's gradient all-reduce."""
+    world, port = 2, _free_port()
+    mp.spawn(_best_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    s0, s1 = (open(tmp_path / f"saved{r}.txt").read() for r in range(world))
+    assert s0 == s1 == repr([("best", 0), ("best", 2), ("last", 2)]), (s0, s1)      # rank 0's metric: improves in epochs 0 and 2

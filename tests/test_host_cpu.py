@@ -74,11 +74,18 @@ def test_masker_bit_exact_vs_reference():
     # token_mask_only keeps the token-level draw (first two generator calls) identical
     c = cases[0]
     a, b = Masker(DictConfig(c["cfg"])), Masker(DictConfig(c["cfg"]))
-    b.token_mask_only = True
     x = torch.from_numpy(z["c0/ap"])
-    torch.manual_seed(3); _, ma = a(x.clone(), np.full((4, 9), "XX"))
-    torch.manual_seed(3); _, mb = b(x.clone(), np.full((4, 9), "XX"))
+    torch.manual_seed(3); xa, ma = a(x.clone(), np.full((4, 9), "XX"))
+    torch.manual_seed(3); xb, mb = b(x.clone(), np.full((4, 9), "XX"), token_mask_only=True)
     assert torch.equal(ma, mb)
+    assert not torch.equal(xa, x) and torch.equal(xb, x)       # the corruption draws are what the switch skips
+    # the switch is a per-call argument: the attribute alone (what a trainer sets) changes nothing for callers that USE the spikes,
+    # and it never survives a pickle (model_best.pt must not carry one run's throughput switch)
+    b.token_mask_only = True
+    torch.manual_seed(3); xc, mc = b(x.clone(), np.full((4, 9), "XX"))
+    assert torch.equal(xc, xa) and torch.equal(mc, ma)
+    import pickle
+    assert pickle.loads(pickle.dumps(b)).token_mask_only is False
 
 
 def test_param_layout_covers_parameters_contiguously():
