@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MMFM_VERSION 300
+#define MMFM_VERSION 400
 #define MMFM_F32 0
 #define MMFM_BF16 1
 
@@ -158,9 +158,19 @@ typedef struct {
     const void* d_o; int lddo;   /* grad wrt the out_proj input (i.e. AFTER drop_o) */
     void* dq; void* dk; void* dv;
     int lddq, lddk, lddv;
+    /* optional (round 4): workspace of mmfm_attn_keepbits_bytes(B, heads, Lq, Lk) bytes for the keep decisions of drop_p, one bit
+     * per (b, head, query, key).  With it, launches the dh = 32 fast kernels take (bf16, Lq <= 256, Lk <= 224, both % 8 == 0, no
+     * CAUSAL / SEP, 16-B aligned operands) draw the decisions ONCE - mmfm_attn_fwd runs a generator kernel in front of the
+     * forward - and mmfm_attn_bwd reads the same bits: the caller leaves the buffer alone between the two calls.  The drop
+     * probability is then honoured to 2^-10: keep = mmfm_attn_keep_prob(drop_p.p), survivors are scaled by 1 / keep.
+     * NULL (or a shape the fast kernels do not take): both directions re-derive the decisions from the counter hash. */
+    void* keepbits;
 } mmfm_attn_desc;
 int mmfm_attn_fwd(const mmfm_attn_desc* d, mmfm_stream stream);
 int mmfm_attn_bwd(const mmfm_attn_desc* d, mmfm_stream stream);
+int64_t mmfm_attn_keepbits_bytes(int B, int heads, int Lq, int Lk);
+/* the keep probability the keep-bit path applies for a drop probability p */
+float mmfm_attn_keep_prob(float p);
 
 /* ---------------------------------------------------------------------------------- masks / stitch
  * mm.py:245-275 (mask = eval_mask[:,:,0] & attn_mask), :102 (mod_mask), :145,167 (sample-0 ids),

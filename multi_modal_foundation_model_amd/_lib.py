@@ -49,7 +49,7 @@ class AttnDesc(C.Structure):
                 ("ldv", C.c_int), ("o", C.c_void_p), ("ldo", C.c_int), ("lse", C.c_void_p), ("keypad", C.c_void_p),
                 ("mod_id", C.c_void_p), ("flags", C.c_int), ("scale", C.c_float), ("drop_p", Dropout),
                 ("drop_o", Dropout), ("d_o", C.c_void_p), ("lddo", C.c_int), ("dq", C.c_void_p), ("dk", C.c_void_p),
-                ("dv", C.c_void_p), ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int)]
+                ("dv", C.c_void_p), ("lddq", C.c_int), ("lddk", C.c_int), ("lddv", C.c_int), ("keepbits", C.c_void_p)]
 
 
 class PrepEntry(C.Structure):
@@ -97,6 +97,8 @@ _PROTOS = {
     "mmfm_layernorm_bwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _i, _i, _i, _vp, _i64, _vp]),
     "mmfm_attn_fwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
     "mmfm_attn_bwd": (C.c_int, [C.POINTER(AttnDesc), _vp]),
+    "mmfm_attn_keepbits_bytes": (C.c_int64, [_i, _i, _i, _i]),
+    "mmfm_attn_keep_prob": (C.c_float, [_f]),
     "mmfm_mask_prep": (C.c_int, [_i, _i, _i, C.POINTER(_vp), C.POINTER(_i64), _vp, C.POINTER(_i64), _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmfm_collate_csr": (C.c_int, [_i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mmfm_stitch_fwd": (C.c_int, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),

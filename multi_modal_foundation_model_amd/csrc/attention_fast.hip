@@ -1,122 +1,157 @@
 // bf16 attention, dh = 32, heads of up to 224 keys / 256 queries (the d_model-256 configurations: L = 200): the straight-line
-// forward and single-pass backward that the step spends its attention time in.  Same contract as attention_bf16.hip
+// forward and the single-pass backward that the step spends its attention time in.  Same contract as attention_bf16.hip
 // (masks: key padding and DIAG; CAUSAL / SEP stay with the general kernels), reference: mm_utils.py:97-152.
 //
-// What changed against the general kernels, and why (round-2 counters: both were VALU-issue bound at 3,780 / 2,660 vector
-// instructions per wave, MFMA pipe 7 % busy):
-//   * attention-probability dropout keeps the counter hash of the general kernels (attn_common.h Drop16: one mix per PAIR of keys
-//     under a per-(batch, head, query) row key, the same decisions bit for bit, so the general single-pass backward pairs with this
-//     forward); both 16-bit fields are compared without extraction (word-select compares) and the selects run on fp32 values
-//     before the PACKED bf16 conversion.  Measured and dropped on the way: a precomputed keep-bit mask
-//     (generator kernel + scalar-loaded lane masks: the generator costs what the in-place hash costs - integer VALU issues at
-//     4 cycles per wave instruction here - and the mask loads put a memory wait into every tile: 293 + 475 us against
-//     264 + 435 us) and decisions taken from an int8 MFMA product of per-query / per-key random vectors (exact in both
-//     orientations, 2 VALU instructions per element instead of 6, but 258 + 465 us: the two dependent MFMAs sit at the head
-//     of every tile of the barrier-synchronised backward).
-//   * masks ride on the MFMA: the score accumulator starts at bias[key] (0 or -inf, an LDS table), so padded keys and the
-//     head's ragged last tile need no compare / select at all, and the code has no per-group branches: the tile body is
-//     instantiated per number of valid 8-key (forward) / 8-query (backward) groups and the loop calls the full one;
-//   * lazy rescaling of the running maximum (threshold 2^6: the accumulator and the running sum are only rescaled when a
-//     row's maximum grows by more than that; the LSE stays exact because m_run is only a reference point);
-//   * the forward runs one query tile per wave with as many waves as the head has tiles (7 at L = 200: no idle eighth wave).
+// Round 4: attention-probability dropout no longer hashes inside these kernels.  Both were VALU-issue bound and the counter
+// hash was 27 % of the forward's vector instructions (479 of 1,768) and ~60 us of every backward launch.  Now a generator kernel
+// draws the keep decisions ONCE per launch as bit tiles (mmfm_attn_desc.keepbits, layout below) - 32 decisions per lane-word by
+// the binary-expansion trick, i.e. at the full width of the vector unit instead of two decisions per 7-instruction hash - and
+//   * the forward reads a tile's 16 lane masks with two scalar loads (s_load_dwordx16) and applies them with one
+//     v_cndmask_b32 per probability: no compare, no hash, no vector register;
+//   * the backward lane (= key) fetches its seven words with the prologue loads and expands a bit per element.
+// Without a keepbits buffer, calls with attention dropout go to the general kernels (attention_bf16.hip), which hash.
+//
+// Keep-bit layout: uint32 words [b * heads + h][qt][kt][32]; word w = 2 r + kh of tile (qt, kt) belongs to key
+// 32 kt + mrow(r, kh) (the key that accumulator register r holds in lane half kh when the lane is the query), bit j of it to
+// query 32 qt + j.  So the forward's lane mask for register r is the 64-bit pair (words 2 r, 2 r + 1) as it lies in memory, and
+// a backward lane (key 32 kt + l, l = mrow(r, kh)) needs word 2 r + kh of each of its query tiles.
+//
+// Kept from round 3: masks ride on the MFMA (the score accumulator starts at bias[key], 0 or -inf), the tile body is instantiated
+// per number of valid 8-row groups, lazy rescaling of the running maximum, one query tile per wave with as many
+// waves as the head has tiles.
 #include "attn_common.h"
 #include <algorithm>
 #include <stdlib.h>
-#include <mutex>
-#include <unordered_map>
 
 using namespace attn;
 
 namespace {
 
-constexpr float LAZY_THR = 6.f;       // log2 units: probabilities stay below 2^6 between rescales
+constexpr int KEEP_BITS = 10;         // the keep probability is honoured to 2^-10 (mmfm_attn_keep_prob)
 
-#ifdef MMFM_ATTN_STAMP
-// diagnostic build only (scripts/probe/build_attn_stamp.sh): shader cycles per phase, one row of 6 per wave (plain stores: an
-// atomic per wave on six shared words made the stamped kernel 25x slower and the shares meaningless), summed on the host
-constexpr int APROBE_ROWS = 8192 * 8;
-__device__ unsigned long long mmfm_attn_probe_acc[APROBE_ROWS * 6];
-#define ASTAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_a[6] = {0, 0, 0, 0, 0, 0}
-#define ASTAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
-                       __builtin_amdgcn_sched_barrier(0); st_a[i] += n_ - st_t; st_t = n_; } while (0)
-#define ASTAMP_FLUSH(base) do { if ((threadIdx.x & 63) == 0) { const int row_ = (int)(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % APROBE_ROWS; \
-                                for (int i_ = 0; i_ < 6; ++i_) mmfm_attn_probe_acc[row_ * 6 + i_] = st_a[i_]; } } while (0)
-#else
-#define ASTAMP_DECL
-#define ASTAMP(i)
-#define ASTAMP_FLUSH(base)
-#endif
-
+// ---------------------------------------------------------------------------------------------- helpers
+// NO vector instruction of these kernels lives in inline asm.  Round 4 tried (v_add / v_max3 / v_cndmask / v_bfe in asm, to keep the
+// compiler from packing fp32 pairs or rewriting a bit test): every launch returned garbage.  gfx950 leaves several read-after-write
+// waits to software (an MFMA's result, a transcendental's, a permlane's) and the compiler inserts them only around instructions it
+// can see.  What shapes the code instead: -fno-slp-vectorize for this file (Makefile: v_pk_*_f32 is 8 issue cycles for two results,
+// no gain beside MFMAs), __builtin_amdgcn_inverse_ballot_w64 for "select by a scalar lane mask" (one v_cndmask_b32 with an SGPR pair),
+// and EMPTY asm statements as optimisation barriers only.
+__device__ __forceinline__ float v_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float v_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float v_mul(float a, float b) { return a * b; }
+// p where the lane's bit of `mask` is set, else 0
+__device__ __forceinline__ float v_keep(float p, uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask) ? p : 0.f; }
 __device__ __forceinline__ float xhalf_max(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    return v_max(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float xhalf_sum(float v) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-// ---------------------------------------------------------------------------------------------- forward
-// One key tile (32 keys x 32 queries, lane = query): online softmax on the scores `st` (bias already inside), dropout,
-// O^T += V^T P^T.  G = 8-key groups of the tile that exist (registers 4g .. 4g+3).  jx = (pair index of the tile's first key of
-// this lane half) ^ row key A, kb = row key B: register pair (r, r+1) = keys (kt*32 + mrow(r, kh), +1) = pair index
-// (16 kt + 2 kh) | (mrow(r, 0) >> 1) - disjoint bits, so each pair costs one XOR with a literal (as in attention_bf16.hip).
-template <int G, bool DROP>
-__device__ __forceinline__ void fwd_tile(const f32x16& st, float c2, float& m_run, float& l_run, f32x16& acc, const Drop16& dp, uint32_t jx,
-                                         uint32_t kb, const char* Vs, int kt, int lane) {
-    float mx = st[0];
+
+// ---------------------------------------------------------------------------------------------- keep-bit generator
+// One thread per 32-decision word.  Bernoulli(keep) bits from uniform words by the binary expansion keep = 0.b1 b2 ... bn:
+// walking the bits from the least significant, r = b ? (u | r) : (u & r) halves the distance to the next digit each time, so after
+// the walk every bit of r is set with probability keep (to 2^-n), independently per bit position.  n uniform words per 32 decisions
+// instead of 16 hashes: 2.4 vector instructions per decision here against 5.5 in the attention kernels' own lanes.
+struct KeepArgs {
+    uint32_t* bits;
+    const uint32_t* state;
+    uint32_t site, thresh;        // thresh = round(keep * 2^KEEP_BITS) in [1, 2^KEEP_BITS - 1]
+    uint32_t nwords;
+};
+__global__ __launch_bounds__(256) void attn_keepbits_kernel(const KeepArgs a) {
+    const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
+    if (gid >= a.nwords) return;
+    const uint32_t k0 = mix32(a.state[0] + a.site * 0x9E3779B9u), k1 = mix32(a.state[1] ^ (a.site * 0x85EBCA6Bu + 0xC2B2AE35u));
+    const uint32_t s = mix32(gid ^ k0);
+    const uint32_t kb = k1 + __umul24(s >> 24, 0x9E3779u);       // v_mul_u32_u24 sees bits 0..23 only: the top byte enters here
+    uint32_t r = 0;
 #pragma unroll
-    for (int r = 1; r < 4 * G; ++r) mx = fmaxf(mx, st[r]);
-    const float mt = xhalf_max(mx) * c2;                       // c2 > 0; identical in both lane halves
-    const bool grow = mt > m_run + LAZY_THR;                   // m_run = -inf: any finite score grows it
-    if (__any(grow)) {
-        const float m_new = grow ? mt : m_run;
-        const float alpha = grow ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] *= alpha;
-        l_run *= alpha;
-        m_run = m_new;
+    for (int j = 0; j < KEEP_BITS; ++j) {
+        if ((a.thresh & ((2u << j) - 1u)) == 0) continue;        // trailing zero digits leave r = 0 (uniform branch)
+        uint32_t h = __umul24(s + (uint32_t)j * 0x3C6EF35Fu, 0x7FEB35u) + kb;
+        h ^= h >> 13;
+        h = __umul24(h, 0x46CA6Bu) ^ (h >> 9);
+        h ^= h >> 16;
+        r = ((a.thresh >> j) & 1u) ? (h | r) : (h & r);
     }
-    const float m_use = (m_run == -INFINITY) ? 0.f : m_run;    // nothing allowed so far: every p below is exp2(-inf) = 0
-    float pd[16];
-    float ps = 0.f;
+    a.bits[gid] = r;
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+// One key tile (32 keys x 32 queries, lane = query): probabilities of the scores `st` (key bias already inside) against the row's
+// reference exponent, dropout, O^T += V^T P^T.  G = 8-key groups of the tile that exist (registers 4g .. 4g+3), mk = the tile's 16
+// lane masks.  nm = -(reference): see the kernel for the two modes.
+struct Masks16 { uint64_t m[16]; };
+typedef const Masks16 __attribute__((address_space(4))) * masks_ptr;      // constant address space: scalar loads
+__device__ __forceinline__ Masks16 ld_masks(masks_ptr p) {
+    Masks16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.m[i] = p->m[i];
+    return r;
+}
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {          // one v_cvt_pk_bf16_f32
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+    bf16x2v v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+template <int G, bool DROP>
+__device__ __forceinline__ void fwd_tile(const f32x16& st, float c2, float nm, float& l_run, f32x16& acc, const Masks16& mk, const char* Vs,
+                                         int kt, int lane) {
+    uint32_t pk[8];                                                                   // the sixteen probabilities, packed as they are made
+    float ps0 = 0.f, ps1 = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
         if (r < 4 * G) {
-            float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, -m_use));
-            float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r + 1], c2, -m_use));
-            ps += p0 + p1;
-            if (DROP) {
-                const uint32_t hsh = dp.hash(jx ^ (uint32_t)(mrow(r, 0) >> 1), kb);
-                p0 = (uint16_t)hsh >= (uint16_t)dp.t16 ? p0 : 0.f;       // the 1/(1-p) factor rides on the final normalisation
-                p1 = (hsh >> 16) >= dp.t16 ? p1 : 0.f;
-                // opaque to the optimiser: otherwise hipcc converts every probability to bf16 on its own, selects on the 16-bit values
-                // and permutes the halves together (16 cvt + 16 select + 8 perm per tile instead of 16 select + 8 packed cvt)
-                asm volatile("" : "+v"(p0), "+v"(p1));
+            float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r], c2, nm));        // -inf scores (padded keys): exp2(-inf) = 0
+            float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(st[r + 1], c2, nm));
+            ps0 = v_add(ps0, p0);
+            ps1 = v_add(ps1, p1);
+            if (DROP) {                                                              // the 1 / keep factor rides on the final normalisation
+                p0 = v_keep(p0, mk.m[r]);
+                p1 = v_keep(p1, mk.m[r + 1]);
             }
-            pd[r] = p0;
-            pd[r + 1] = p1;
+            // Opaque to the optimiser, no instruction inside.  (i) Without it every probability is converted to bf16 on its own, selected
+            // as a 16-bit value and the halves permuted together (16 cvt + 16 select + 8 perm per tile instead of 16 select + 8 packed cvt).
+            // (ii) The running sums pass through it too: left alone, the row-sum adds (a dependent chain) sink to the end of the tile, all
+            // sixteen exponentials stay alive for them and the straight-line kernel spills 50 registers.
+            asm volatile("" : "+v"(p0), "+v"(p1), "+v"(ps0), "+v"(ps1));
+            pk[r >> 1] = pack2(p0, p1);
         } else {
-            pd[r] = 0.f;
-            pd[r + 1] = 0.f;
+            pk[r >> 1] = 0u;
         }
     }
-    l_run += ps;
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, 64, kt * 32, 0, lane), pack8(pd), acc, 0, 0, 0);
-    if (G > 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, 64, kt * 32 + 16, 0, lane), pack8(pd + 8), acc, 0, 0, 0);
+    l_run = v_add(l_run, v_add(ps0, ps1));
+    const uint4 lo = make_uint4(pk[0], pk[1], pk[2], pk[3]), hi = make_uint4(pk[4], pk[5], pk[6], pk[7]);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, 64, kt * 32, 0, lane), __builtin_bit_cast(bf16x8v, lo), acc, 0, 0, 0);
+    if (G > 2) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Vs, 64, kt * 32 + 16, 0, lane), __builtin_bit_cast(bf16x8v, hi), acc, 0, 0, 0);
+}
+template <int G>
+__device__ __forceinline__ float tile_max(const f32x16& st) {
+    float mx = fmaxf(fmaxf(st[0], st[1]), st[2]);
+#pragma unroll
+    for (int r = 3; r < 4 * G; ++r) mx = fmaxf(mx, st[r]);
+    return xhalf_max(mx);                                      // identical in both lane halves
 }
 
-constexpr int F_KRS = 80, F_VRS = 64, F_ORS = 80;
+constexpr int F_KRS = 80, F_VRS = 64, F_ORS = 80, F_MAXKT = 7;
+constexpr float F_OVERFLOW = 1.2676506e30f;                    // 2^100: a row sum beyond it sends the wave to the exact pass
 
-template <int NW, bool DROP>
-__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_fast_kernel(const mmfm_attn_desc d) {
+// NKT = key tiles of the head when known at compile time (7: the L = 200 / 224 step shapes), 0 = read from the descriptor.
+template <int NW, bool DROP, int NKT>
+__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_fast_kernel(const mmfm_attn_desc d, const float keep_scale) {
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, kh = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int bh_ = attn_xcd_remap((int)blockIdx.x, (int)gridDim.x, d.flags);
     const int b = bh_ / d.heads, h = bh_ % d.heads;
-    const int Lq = d.Lq, Lk = d.Lk, LkP = (Lk + 31) & ~31;
-    const int nqt = (Lq + 31) >> 5, nkt = LkP >> 5;
+    const int Lq = d.Lq, Lk = d.Lk, LkP = NKT ? NKT * 32 : (Lk + 31) & ~31;
+    const int nqt = (Lq + 31) >> 5, nkt = NKT ? NKT : LkP >> 5;
     char* Ks = smem;
     char* Vs = Ks + LkP * F_KRS;
     float* kbias = reinterpret_cast<float*>(Vs + LkP * F_VRS);
@@ -126,14 +161,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_fast_kernel(const mmfm_at
     const uint16_t* qg = reinterpret_cast<const uint16_t*>(d.q) + (size_t)b * Lq * d.ldq + h * 32;
     const uint16_t* kg = reinterpret_cast<const uint16_t*>(d.k) + (size_t)b * Lk * d.ldk + h * 32;
     const uint16_t* vg = reinterpret_cast<const uint16_t*>(d.v) + (size_t)b * Lk * d.ldv + h * 32;
-    uint16_t* og = reinterpret_cast<uint16_t*>(d.o) + (size_t)b * Lq * d.ldo + h * 32;
 
-    ASTAMP_DECL;
     // ONE memory round trip for the whole prologue: every global load of the workgroup (K and V chunks, the key-padding bytes, the
-    // wave's own Q rows) is issued before the first wait.  (The generic loader - a load followed by its LDS store per loop trip - made
-    // five to six DEPENDENT round trips of ~1.5 us each: half of a wave's 12 us life, see scripts/probe/attn_stamp.py.)
-    // Chunk c = t + NT j (j = 0, 1; LkP * 4 <= 2 NT for every NW the launcher picks): row c >> 2, 16-B column c & 3; rows >= Lk are
-    // zero-filled (a NaN bit pattern left in LDS would survive the -inf bias / the zero probability).
+    // wave's own Q rows) is issued before the first wait.  Chunk c = t + NT j (j = 0, 1; LkP * 4 <= 2 NT for every NW the launcher
+    // picks): row c >> 2, 16-B column c & 3; rows >= Lk are zero-filled (a NaN bit pattern left in LDS would survive the -inf bias /
+    // the zero probability).
     const int qt = wave;
     const int q0 = qt * 32, q = q0 + l31;
     uint4 kc[2], vc[2], qv[2];
@@ -164,86 +196,117 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_fast_kernel(const mmfm_at
     const bool kok = t < Lk && kpv != 0;
     if (t < LkP) kbias[t] = kok ? 0.f : -INFINITY;
     const int pad = (t < Lk && !kok) ? 1 : 0;
-    ASTAMP(0);
     const int wv = __any(pad) ? 1 : 0;                  // all 64 lanes vote before any divergence
     if (lane == 0) wflag[wave] = wv;
     __syncthreads();                                    // also: the images are complete
     int anypad = 0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) anypad |= wflag[w];
+    anypad = __builtin_amdgcn_readfirstlane(anypad);     // the same word in every lane: tell the compiler, or `dfix` is a divergent branch
     if (qt >= nqt) return;
-    ASTAMP(1);
 
     bf16x8v qf[2];
     qf[0] = __builtin_bit_cast(bf16x8v, qv[0]);
     qf[1] = __builtin_bit_cast(bf16x8v, qv[1]);
     const float c2 = d.scale * LOG2E;
-    const Drop16 dp = drop16_init(d.drop_p);
-    uint32_t ka = 0, kb = 0;                                    // dropout row keys of this lane's query
-    if (DROP) dp.rowkeys((uint32_t)bh_ * (uint32_t)Lq + (uint32_t)q, ka, kb);
     const bool fixdiag = anypad && (d.flags & MMFM_ATTN_DIAG);
+    // the wave's keep-bit tiles: [bh][qt][kt] x 128 B, wave-uniform addresses
+    const masks_ptr mkp = reinterpret_cast<masks_ptr>(reinterpret_cast<uintptr_t>(d.keepbits)) + ((size_t)bh_ * nqt + qt) * nkt;
 
     // S^T tile: rows = keys (registers), lane = query; the accumulator starts at the key bias
     auto score = [&](int kt) {
-        // rare: padded keys in the head and `eye |` (a query always sees itself): the diagonal tile starts from zero and takes the
-        // key bias after the product, except on the diagonal
+        // rare: padded keys in the head and `eye |` (a query always sees itself): the diagonal tile drops the key bias on the diagonal
         const bool dfix = fixdiag && kt == qt;
         f32x16 a;
-        if (!dfix) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 kb4 = *reinterpret_cast<const float4*>(kbias + kt * 32 + 8 * g + 4 * kh);
-                a[4 * g + 0] = kb4.x; a[4 * g + 1] = kb4.y; a[4 * g + 2] = kb4.z; a[4 * g + 3] = kb4.w;
-            }
-        } else {
+        for (int g = 0; g < 4; ++g) {
+            const float4 kb4 = *reinterpret_cast<const float4*>(kbias + kt * 32 + 8 * g + 4 * kh);
+            a[4 * g + 0] = kb4.x; a[4 * g + 1] = kb4.y; a[4 * g + 2] = kb4.z; a[4 * g + 3] = kb4.w;
+        }
+        if (dfix) {
+            asm volatile("" ::: "memory");               // keeps this a branch: as selects it costs every tile 16 instructions and 32 SGPRs
 #pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] = 0.f;
+            for (int r = 0; r < 16; ++r) a[r] = (mrow(r, kh) == l31) ? 0.f : a[r];
         }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
             a = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Ks, (kt * 32 + l31) * F_KRS + ks * 32 + kh * 16), qf[ks], a, 0, 0, 0);
-        if (dfix) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) a[r] += (mrow(r, kh) == l31) ? 0.f : kbias[kt * 32 + mrow(r, kh)];
-        }
         return a;
     };
-    float m_run = -INFINITY, l_run = 0.f;
+    const int gtail = ((Lk - (nkt - 1) * 32) + 7) >> 3;             // 1..4 valid groups in the last key tile (Lk % 8 == 0: launcher)
+    float m_ref, l_run = 0.f;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const int gtail = ((Lk - (nkt - 1) * 32) + 7) >> 3;             // 1..4 valid groups in the last key tile (Lk % 8 == 0: launcher)
-    auto tile = [&](int kt, const f32x16& st) {
-        const uint32_t jx = (uint32_t)(16 * kt + 2 * kh) ^ ka;
+    auto tile = [&](int kt, const f32x16& st, const Masks16& mk) {
         if (kt == nkt - 1 && gtail != 4) {
-            if (gtail == 1) fwd_tile<1, DROP>(st, c2, m_run, l_run, acc, dp, jx, kb, Vs, kt, lane);
-            else if (gtail == 2) fwd_tile<2, DROP>(st, c2, m_run, l_run, acc, dp, jx, kb, Vs, kt, lane);
-            else fwd_tile<3, DROP>(st, c2, m_run, l_run, acc, dp, jx, kb, Vs, kt, lane);
+            if (gtail == 1) fwd_tile<1, DROP>(st, c2, -m_ref, l_run, acc, mk, Vs, kt, lane);
+            else if (gtail == 2) fwd_tile<2, DROP>(st, c2, -m_ref, l_run, acc, mk, Vs, kt, lane);
+            else fwd_tile<3, DROP>(st, c2, -m_ref, l_run, acc, mk, Vs, kt, lane);
         } else {
-            fwd_tile<4, DROP>(st, c2, m_run, l_run, acc, dp, jx, kb, Vs, kt, lane);
+            fwd_tile<4, DROP>(st, c2, -m_ref, l_run, acc, mk, Vs, kt, lane);
         }
     };
-    // two score tiles in flight, ping-pong: tile kt+1's MFMAs are issued before the element-wise work of tile kt
-    f32x16 s0 = score(0), s1;
-    ASTAMP(2);
-    for (int kt = 0; kt < nkt; kt += 2) {
-        const bool has1 = kt + 1 < nkt;
-        if (has1) s1 = score(kt + 1);
-        tile(kt, s0);
-        if (has1) {
-            if (kt + 2 < nkt) s0 = score(kt + 2);
-            tile(kt + 1, s1);
+    // FAST PASS.  The reference exponent of a row is the maximum of its FIRST key tile and stays put: no running maximum, no
+    // rescaling of the output tile, nothing per tile but the probabilities themselves (the element-wise work of this kernel is what
+    // bounds it: 16 instructions per score in round 3, of which the max / rescale bookkeeping and the copies it caused were 4).
+    // Later scores may exceed the reference: fp32 (and the bf16 operand of P.V) carry 2^127, the LSE below is exact for any
+    // reference, and a row whose sum passes 2^100 - a score 69 above everything in the first 32 keys, or a first tile with no
+    // allowed key - sends the whole wave through the exact pass below instead.
+    // Straight-line code over the key tiles: two score tiles and two mask tiles in flight, ping-pong (tile kt+1's MFMAs and scalar
+    // loads are issued before the element-wise work of tile kt).
+    {
+        Masks16 mk[2];
+        f32x16 sc[2];
+        if (DROP) mk[0] = ld_masks(mkp);
+        sc[0] = score(0);
+        m_ref = v_max((nkt == 1 && gtail != 4) ? (gtail == 1 ? tile_max<1>(sc[0]) : gtail == 2 ? tile_max<2>(sc[0]) : tile_max<3>(sc[0]))
+                                                : tile_max<4>(sc[0]), -1e30f / c2) * c2;
+#pragma unroll
+        for (int kt = 0; kt < F_MAXKT; ++kt) {
+            if (kt + 1 < nkt) {
+                sc[(kt + 1) & 1] = score(kt + 1);
+                if (DROP) mk[(kt + 1) & 1] = ld_masks(mkp + (kt + 1));
+            }
+            tile(kt, sc[kt & 1], mk[kt & 1]);
+            if (kt + 1 >= nkt) break;
         }
     }
-    ASTAMP(3);
-    const Drop dout = drop_init(d.drop_o);
-    const float dscale = DROP ? dp.scale : 1.f;
-    const float l_tot = xhalf_sum(l_run);
-    const float inv = dscale / l_tot;
-    if (kh == 0 && q < Lq) d.lse[(size_t)bh_ * Lq + q] = m_run * LN2 + __logf(l_tot);
+    float l_tot = xhalf_sum(l_run);
+    if (__any(!(l_tot < F_OVERFLOW))) {
+        // EXACT PASS (rare; also taken by NaN inputs, once): running maximum per tile, output tile rescaled every tile.
+        float m_run = -1e30f;
+        l_run = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            const f32x16 st = score(kt);
+            Masks16 mk;
+            if (DROP) mk = ld_masks(mkp + kt);
+            const float mt = tile_max<4>(st) * c2;          // padded rows of a ragged last tile carry the -inf bias: no effect on the maximum
+            const float m_new = v_max(m_run, mt);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] *= alpha;
+            l_run *= alpha;
+            m_run = m_new;
+            m_ref = m_run;
+            tile(kt, st, mk);
+        }
+        l_tot = xhalf_sum(l_run);
+    }
+    // everything the epilogue needs from the descriptor is read HERE, from the kernel-argument segment: held across the tile loop these
+    // pointers and strides, together with two tiles of lane masks (64 scalar registers), overflow the scalar file into vector lanes
+    const mmfm_attn_desc* kd = (const mmfm_attn_desc*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kd));
+    const Drop dout = drop_init(kd->drop_o);
+    const float inv = keep_scale / l_tot;
+    if (kh == 0 && q < Lq) kd->lse[(size_t)bh_ * Lq + q] = m_ref * LN2 + __logf(l_tot);
     // O^T (rows = d in registers, lane = query) -> bf16 rows [query][d] through the wave's staging tile, output dropout on the way
     char* tl = ost + wave * 32 * F_ORS;
-    const uint64_t base = ((uint64_t)b * Lq + (uint64_t)q) * (uint64_t)(d.heads * 32) + (uint64_t)(h * 32);
+    const int heads = kd->heads, ldo = kd->ldo;
+    uint16_t* og = reinterpret_cast<uint16_t*>(kd->o) + (size_t)b * Lq * ldo + h * 32;
+    const uint64_t base = ((uint64_t)b * Lq + (uint64_t)q) * (uint64_t)(heads * 32) + (uint64_t)(h * 32);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         const int d0 = 8 * g + 4 * kh;
@@ -262,10 +325,8 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_fast_kernel(const mmfm_at
     for (int i = 0; i < 2; ++i) {
         const int idx = lane + 64 * i, row = idx >> 2, c = idx & 3;
         if (q0 + row < Lq)
-            *reinterpret_cast<uint4*>(og + (size_t)(q0 + row) * d.ldo + 8 * c) = *reinterpret_cast<const uint4*>(tl + row * F_ORS + c * 16);
+            *reinterpret_cast<uint4*>(og + (size_t)(q0 + row) * ldo + 8 * c) = *reinterpret_cast<const uint4*>(tl + row * F_ORS + c * 16);
     }
-    ASTAMP(4);
-    ASTAMP_FLUSH(0);
 }
 
 size_t fwd_fast_lds(int Lk, int nw) {
@@ -274,39 +335,82 @@ size_t fwd_fast_lds(int Lk, int nw) {
 }
 
 // ---------------------------------------------------------------------------------------------- backward (single pass)
-// Structure of attn_bwd1_bf16_kernel (attention_bf16.hip): compute waves 0..6 own one 32-key tile each (lane = key; dK^T, dV^T
-// in accumulators) and walk the query tiles in lock step, dropping their packed dS^T tile into an LDS staging slot; wave 7
-// turns the staged tiles of the previous query tile into dQ.  One barrier per query tile; fixed order, no atomics.
-constexpr int B_NW = 8, B_CW = 7, B_TS = 80, B_TILE = 32 * B_TS, B_RS = 80;
+// Compute waves 0..6 own one 32-key tile each (lane = key; dK^T, dV^T in accumulators) and walk the query tiles, dropping their
+// packed dS^T tile into an LDS staging slot; wave 7 turns the staged tiles of a query tile into dQ.  Fixed order, no atomics.
+// Round 4:
+//   * the Q / dO images are DENSE 64-byte rows with the 16-byte chunk index XOR-ed by (row >> 2) & 3: the row reads (ds_read_b128,
+//     S and dP operands) and the transposed reads (ds_read_b64_tr_b16, dK^T / dV^T operands: 4 rows x 64 B = all 64 banks once) are
+//     both conflict free; the 80-byte rows of round 3 cost the transposed reads a third cycle (SQ_LDS_BANK_CONFLICT was 35 % of
+//     SQ_LDS_IDX_ACTIVE);
+//   * dropout decisions come from the forward's keep bits: a lane (= key) loads its word of every query tile with the prologue
+//     loads (<= 8 dwords) and expands one bit per element (v_bfe_i32 -> and);
+//   * SYNC = 1: no workgroup barrier in the query-tile loop.  A compute wave publishes "tile qt staged" in its own LDS word and
+//     only waits for wave 7 to have drained the slot it is about to overwrite (two steps back), wave 7 waits for the seven words:
+//     the compute waves no longer run in lock step (they contend for the same pipe at the same time when they do).
+constexpr int B_NW = 8, B_CW = 7, B_TS = 80, B_TILE = 32 * B_TS, B_RS = 64, B_QRS = 80;
+constexpr int B_SPIN = 1 << 22;                      // bound of every flag wait: a lost hand-off ends in wrong numbers, never in a hang
 
-// one query tile of a compute wave (lane = key, rows = queries), no attention dropout (with it the general single-pass kernel of
-// attention_bf16.hip runs: see the header).  GRP = 8-query groups of the tile that exist (registers 4g .. 4g+3 = queries
-// 8g + 4 kh + 0..3).
-template <int GRP>
-__device__ __forceinline__ void bwd_tile(const f32x16& s, const f32x16& dpv, float c2, const float2* ldl, const char* As, const char* Bs, char* slot,
-                                         int qt, int kh, int lane, f32x16& dKt, f32x16& dVt) {
+__device__ __forceinline__ int img_off(int row, int chunk) { return row * B_RS + ((chunk ^ ((row >> 2) & 3)) << 4); }
+// transposed operand out of a swizzled dense image: element j = image[rbase + 8 (j >> 2) + 4 h + (j & 3)][c]   (rbase % 16 == 0)
+__device__ __forceinline__ bf16x8v trfrag_sw(const char* S, int rbase, int lane) {
+    const int g = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+    const int r0 = 4 * (g >> 1) + q;                                    // 0..7; the second half reads row r0 + 8
+    const int chunk = 2 * (g & 1) + (p >> 1), byte = 8 * (p & 1);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(S + (rbase + r0) * B_RS + ((chunk ^ (g >> 1)) << 4) + byte));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(S + (rbase + r0 + 8) * B_RS + ((chunk ^ ((g >> 1) + 2)) << 4) + byte));
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8v, v);
+}
+
+__device__ __forceinline__ uint32_t lds_flag_load(const uint32_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_flag_store(uint32_t* p, uint32_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// one query tile of a compute wave (lane = key, rows = queries).  GRP = 8-query groups of the tile that exist (registers 4g .. 4g+3 =
+// queries 8g + 4 kh + 0..3).  wsh = the lane's keep word of this query tile, shifted so that bit (r & 3) + 8 (r >> 2) is register r's.
+template <int GRP, bool DROP>
+__device__ __forceinline__ void bwd_tile(const f32x16& s, const f32x16& dpv, float c2, const float* lse2, const float* dl, uint32_t wsh,
+                                         const char* As, const char* Bs, char* slot, int qt, int kh, int lane, f32x16& dKt, f32x16& dVt) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
         if (2 * s2 >= GRP) continue;
         const bool both = GRP > 2 * s2 + 1;
         float pd[8], ds[8];
-        const float2* lq = ldl + qt * 32 + 16 * s2 + 4 * kh;          // (lse * log2 e, delta) of the half tile's queries
+        const int qb = qt * 32 + 16 * s2 + 4 * kh;                    // the half tile's queries: qb + 0..3 and qb + 8 + 0..3
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            if (e >= 4 && !both) { pd[e] = 0.f; ds[e] = 0.f; continue; }
-            const int r = 8 * s2 + e;
-            const float2 ld = lq[(e & 3) + 8 * (e >> 2)];
-            const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -ld.x));
-            pd[e] = p;
-            ds[e] = p * (dpv[r] - ld.y);
+        for (int e4 = 0; e4 < 2; ++e4) {
+            if (e4 == 1 && !both) {
+#pragma unroll
+                for (int e = 4; e < 8; ++e) { pd[e] = 0.f; ds[e] = 0.f; }
+                continue;
+            }
+            const float4 l4 = *reinterpret_cast<const float4*>(lse2 + qb + 8 * e4), d4 = *reinterpret_cast<const float4*>(dl + qb + 8 * e4);
+            const float lq[4] = {l4.x, l4.y, l4.z, l4.w}, dq_[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = 4 * e4 + i, r = 8 * s2 + e;
+                const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -lq[i]));
+                float pm = p;
+                if (DROP) {
+                    int m = __builtin_amdgcn_sbfe((int)wsh, (r & 3) + 8 * (r >> 2), 1);     // 0 or ~0: v_bfe_i32
+                    asm volatile("" : "+v"(m));                        // opaque: else the optimiser turns bfe + and into test + compare + select
+                    pm = __uint_as_float(__float_as_uint(p) & (uint32_t)m);
+                }
+                pd[e] = pm;                                            // kept probabilities (unscaled): dV's operand
+                ds[e] = __builtin_fmaf(pm, dpv[r], -v_mul(p, dq_[i])); // dS / dropout scale = p (m dP - delta / scale)
+            }
         }
         const bf16x8v pf = pack8(pd), sf = pack8(ds);
         // dS^T[key = lane][q]: elements 0..3 are queries 16*s2 + 4*kh + 0..3, elements 4..7 the same + 8
         const uint4 sw = __builtin_bit_cast(uint4, sf);
         *reinterpret_cast<uint2*>(slot + (16 * s2 + 4 * kh) * 2) = make_uint2(sw.x, sw.y);
         *reinterpret_cast<uint2*>(slot + (16 * s2 + 8 + 4 * kh) * 2) = make_uint2(sw.z, sw.w);
-        dVt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(Bs, B_RS, qt * 32 + 16 * s2, 0, lane), pf, dVt, 0, 0, 0);
-        dKt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag(As, B_RS, qt * 32 + 16 * s2, 0, lane), sf, dKt, 0, 0, 0);
+        dVt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_sw(Bs, qt * 32 + 16 * s2, lane), pf, dVt, 0, 0, 0);
+        dKt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(trfrag_sw(As, qt * 32 + 16 * s2, lane), sf, dKt, 0, 0, 0);
     }
     if (GRP <= 2) {                                    // the dQ wave reads whole tiles: the second half must not be stale
         *reinterpret_cast<uint2*>(slot + (16 + 4 * kh) * 2) = make_uint2(0u, 0u);
@@ -314,32 +418,37 @@ __device__ __forceinline__ void bwd_tile(const f32x16& s, const f32x16& dpv, flo
     }
 }
 
-__global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_attn_desc d) {
+// NQT = query tiles of the head when known at compile time (7: the L = 200 / 224 step shapes - the query-tile loop is then straight-line
+// code and every LDS address in it a lane constant plus an immediate), 0 = read from the descriptor.
+template <bool DROP, int SYNC, int NQT>
+__global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_attn_desc d, const float keep_scale) {
     constexpr int NW = B_NW, CW = B_CW, TS = B_TS, TILE = B_TILE, RS = B_RS, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, kh = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int bh_ = attn_xcd_remap((int)blockIdx.x, (int)gridDim.x, d.flags);
     const int b = bh_ / d.heads, h = bh_ % d.heads;
-    const int Lq = d.Lq, Lk = d.Lk, LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31;
-    char* As = smem;                                  // Q image
+    const int Lq = d.Lq, Lk = d.Lk, LqP = NQT ? NQT * 32 : (Lq + 31) & ~31, LkP = NQT ? NQT * 32 : (Lk + 31) & ~31;    // NQT: the carve-up
+    const int nqt = NQT ? NQT : LqP / 32, nkt = ((Lk + 31) & ~31) / 32;        // nkt <= min(CW, nqt) (launcher)            // is a constant
+    char* As = smem;                                  // Q image (dense swizzled rows)
     char* Bs = As + LqP * RS;                         // dO image (output dropout applied)
-    float2* ldl = reinterpret_cast<float2*>(Bs + LqP * RS);   // per query: (lse * log2 e, delta / dropout scale)
-    float* kbias = reinterpret_cast<float*>(ldl + LqP);
+    float* lse2 = reinterpret_cast<float*>(Bs + LqP * RS);   // per query: lse * log2 e
+    float* dl = lse2 + LqP;                           // per query: delta / dropout scale
+    float* kbias = dl + LqP;
     char* stg = reinterpret_cast<char*>(kbias + LkP); // [2][CW][32 keys x TS] dS^T tiles; first the K image (prologue only)
-    char* sc7 = stg + 2 * CW * TILE;                  // [32 x RS] dQ transpose tile of wave 7
-    int* wflag = reinterpret_cast<int*>(sc7 + 32 * RS);
+    char* sc7 = stg + 2 * CW * TILE;                  // [32 x B_QRS] dQ transpose tile of wave 7
+    uint32_t* flags = reinterpret_cast<uint32_t*>(sc7 + 32 * B_QRS);      // [0..7]: pad votes; [8..15]: staged[w]; [16]: drained
     const uint16_t* qg = reinterpret_cast<const uint16_t*>(d.q) + (size_t)b * Lq * d.ldq + h * 32;
     const uint16_t* kg = reinterpret_cast<const uint16_t*>(d.k) + (size_t)b * Lk * d.ldk + h * 32;
     const uint16_t* vg = reinterpret_cast<const uint16_t*>(d.v) + (size_t)b * Lk * d.ldv + h * 32;
     const uint16_t* og = reinterpret_cast<const uint16_t*>(d.o) + (size_t)b * Lq * d.ldo + h * 32;
     const uint16_t* dog = reinterpret_cast<const uint16_t*>(d.d_o) + (size_t)b * Lq * d.lddo + h * 32;
-    // the softmax scale stays out of the per-element algebra: dK / dQ are scaled once, when stored
-    const float osc_dk = d.scale;
+    // the softmax scale and the dropout scale stay out of the per-element algebra: dK / dQ / dV are scaled once, when stored
+    const float osc_dk = d.scale * keep_scale, osc_dv = keep_scale, inv_keep = 1.f / keep_scale;
     const Drop dout = drop_init(d.drop_o);
 
-    // ONE memory round trip for the prologue (see the forward): all of Q, K, d_o, o of the head, the LSE row, the key-padding bytes
-    // and the compute waves' own K / V operand rows are requested before the first wait.  Chunk c = t + 512 j (j = 0, 1):
+    // ONE memory round trip for the prologue (see the forward): all of Q, K, d_o, o of the head, the LSE row, the key-padding bytes,
+    // the compute waves' own K / V operand rows and keep words are requested before the first wait.  Chunk c = t + 512 j (j = 0, 1):
     // row c >> 2, 16-B column c & 3 (LkP <= LqP <= 256 -> LqP * 4 <= 1024).
     const int kt_own = wave < CW ? wave : 0, key_own = kt_own * 32 + l31;
     uint4 qc[2], kc[2], gc[2], oc[2], kfv[2], vfv[2];
@@ -362,6 +471,13 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
             vfv[ks] = *reinterpret_cast<const uint4*>(vg + (size_t)key_own * d.ldv + ks * 16 + 8 * kh);
         }
     }
+    // keep words of (query tile i, this wave's key tile): key l31 = mrow(r, kh') sits in word 2 r + kh' of its tile.  The word of
+    // tile 0 comes with the prologue loads, tile qt + 1's is requested while tile qt is worked on (L2-resident: the forward wrote them)
+    const uint32_t* kbp = reinterpret_cast<const uint32_t*>(d.keepbits) + ((size_t)bh_ * nqt * nkt + min(kt_own, nkt - 1)) * 32 +
+                          2 * ((l31 & 3) + 4 * (l31 >> 3)) + ((l31 >> 2) & 1);
+    const int kw_stride = nkt * 32;
+    uint32_t kw_next = 0u;
+    if (DROP) kw_next = kbp[0];
     float lsev = 0.f;
     uint8_t kpv = 1;
     if (t < Lq) lsev = d.lse[(size_t)bh_ * Lq + t];                               // NT = 512 >= LqP >= LkP
@@ -370,7 +486,7 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
     for (int j = 0; j < 2; ++j) {
         const int c = t + NT * j, row = c >> 2, col = c & 3;
         if (row < LqP) {
-            *reinterpret_cast<uint4*>(As + row * RS + col * 16) = qc[j];
+            *reinterpret_cast<uint4*>(As + img_off(row, col)) = qc[j];
             // dO = dropout'(d_o) as bf16;  delta = rowsum(d_o * o) / dropout scale (the four 16-B columns of a row sit in neighbouring lanes)
             const uint32_t gw[4] = {gc[j].x, gc[j].y, gc[j].z, gc[j].w}, ow[4] = {oc[j].x, oc[j].y, oc[j].z, oc[j].w};
             const uint64_t base = ((uint64_t)b * Lq + (uint64_t)row) * (uint64_t)(d.heads * 32) + (uint64_t)(h * 32 + 8 * col);
@@ -386,28 +502,25 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
             }
             part += __shfl_xor(part, 1);
             part += __shfl_xor(part, 2);
-            if (col == 0) ldl[row].y = part;
-            *reinterpret_cast<uint4*>(Bs + row * RS + col * 16) = __builtin_bit_cast(uint4, pack8(gd));
+            if (col == 0) dl[row] = part * inv_keep;
+            *reinterpret_cast<uint4*>(Bs + img_off(row, col)) = __builtin_bit_cast(uint4, pack8(gd));
         }
-        if (row < LkP) *reinterpret_cast<uint4*>(stg + row * RS + col * 16) = kc[j];     // K image, for wave 7's K^T operands only
+        if (row < LkP) *reinterpret_cast<uint4*>(stg + img_off(row, col)) = kc[j];     // K image, for wave 7's K^T operands only
     }
-    if (t < LqP) {
-        *reinterpret_cast<uint4*>(As + t * RS + 64) = make_uint4(0u, 0u, 0u, 0u);        // the 16-B row pads (read by nobody, kept finite)
-        *reinterpret_cast<uint4*>(Bs + t * RS + 64) = make_uint4(0u, 0u, 0u, 0u);
-        ldl[t].x = lsev * LOG2E;
-    }
+    if (t < LqP) lse2[t] = lsev * LOG2E;
     const bool kok = t < Lk && kpv != 0;
     if (t < LkP) kbias[t] = kok ? 0.f : -INFINITY;
     const int pad = (t < Lk && !kok) ? 1 : 0;
     const int wv = __any(pad) ? 1 : 0;
-    if (lane == 0) wflag[wave] = wv;
+    if (lane == 0) flags[wave] = (uint32_t)wv;
     __syncthreads();
     int anypad = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) anypad |= wflag[w];
-    const bool fixdiag = anypad && (d.flags & MMFM_ATTN_DIAG);
-    const int nqt = LqP / 32, nkt = LkP / 32;        // nkt <= CW (launcher)
+    for (int w = 0; w < NW; ++w) anypad |= (int)flags[w];
+    anypad = __builtin_amdgcn_readfirstlane(anypad);
     const float c2 = d.scale * LOG2E;
+    uint32_t* staged = flags + 8;                     // staged[w] = query tiles wave w has staged
+    uint32_t* drained = flags + 16;                   // query tiles wave 7 has drained
 
     if (wave < CW) {
         // ---------------- compute waves: one key tile each, all query tiles
@@ -425,46 +538,78 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
         }
         const float kbv = active ? kbias[key] : 0.f;
         f32x16 s, dpv;
+        // lane-constant part of the operand row addresses (row 32 qt + l31 of a swizzled image: + qt * 2048 per tile)
+        const int roff0 = l31 * RS + (((0 + kh) ^ ((l31 >> 2) & 3)) << 4), roff1 = l31 * RS + (((2 + kh) ^ ((l31 >> 2) & 3)) << 4);
         auto scoresA = [&](int qt) {
-            // rare: padded keys and `eye |`: S[q][q] is allowed even when key q is padded - the diagonal tile takes the bias afterwards
-            const bool dfix = fixdiag && qt == kt;
-            const float s_init = dfix ? 0.f : kbv;
+            const char* Aq = As + qt * (32 * RS);
+            const char* Bq = Bs + qt * (32 * RS);
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (!anypad) {
+                // no padded key in this head (the usual case): both products start from the literal zero, no register is initialised
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Aq, roff0), kfr[0], zero, 0, 0, 0);               // S[q][key]
+                dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Bq, roff0), vfr[0], zero, 0, 0, 0);             // dP[q][key]
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Aq, roff1), kfr[1], s, 0, 0, 0);
+                dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Bq, roff1), vfr[1], dpv, 0, 0, 0);
+            } else {
+                // the key bias (0 / -inf) is the S accumulator's initial value; with `eye |` the diagonal tile keeps S[q][q] finite
+                const bool dfix = (d.flags & MMFM_ATTN_DIAG) && qt == kt;
+                int lv = l31;
+                asm volatile("" : "+v"(lv));            // keeps the diagonal selects inside this (rare) branch instead of 16 hoisted registers
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = s_init; dpv[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int off = (qt * 32 + l31) * RS + ks * 32 + kh * 16;
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(As, off), kfr[ks], s, 0, 0, 0);        // S[q][key]
-                dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Bs, off), vfr[ks], dpv, 0, 0, 0);    // dP[q][key]
-            }
-            if (dfix) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[r] += (mrow(r, kh) == l31) ? 0.f : kbv;
+                for (int r = 0; r < 16; ++r) s[r] = (dfix && mrow(r, kh) == lv) ? 0.f : kbv;
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Aq, roff0), kfr[0], s, 0, 0, 0);
+                dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Bq, roff0), vfr[0], zero, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Aq, roff1), kfr[1], s, 0, 0, 0);
+                dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rowfrag(Bq, roff1), vfr[1], dpv, 0, 0, 0);
             }
         };
         const int gtail = ((Lq - (nqt - 1) * 32) + 7) >> 3;            // valid 8-query groups of the last query tile (Lq % 8 == 0)
+        if (SYNC) {
+            if (lane == 0) { staged[wave] = 0u; if (wave == 0) *drained = 0u; }
+        }
         __syncthreads();                               // wave 7 has its K^T operands: the K image is dead, the staging slots free
-        for (int qt = 0; qt < nqt; ++qt) {
+        auto step = [&](int qt) {
             if (active) {
                 scoresA(qt);
+                uint32_t wq = 0u;
+                if (DROP) {
+                    wq = kw_next >> (4 * kh);          // bit (r & 3) + 8 (r >> 2) is now register r's query
+                    kw_next = kbp[(size_t)min(qt + 1, nqt - 1) * kw_stride];
+                }
+                if (SYNC && qt >= 2) {                 // the slot still holds tile qt - 2 until wave 7 has its operands
+                    for (int spin = 0; spin < B_SPIN && lds_flag_load(drained) < (uint32_t)(qt - 1); ++spin) __builtin_amdgcn_s_sleep(1);
+                }
                 char* slot = stg + ((qt & 1) * CW + wave) * TILE + l31 * TS;
                 if (qt == nqt - 1 && gtail != 4) {
-                    if (gtail == 1) bwd_tile<1>(s, dpv, c2, ldl, As, Bs, slot, qt, kh, lane, dKt, dVt);
-                    else if (gtail == 2) bwd_tile<2>(s, dpv, c2, ldl, As, Bs, slot, qt, kh, lane, dKt, dVt);
-                    else bwd_tile<3>(s, dpv, c2, ldl, As, Bs, slot, qt, kh, lane, dKt, dVt);
+                    if (gtail == 1) bwd_tile<1, DROP>(s, dpv, c2, lse2, dl, wq, As, Bs, slot, qt, kh, lane, dKt, dVt);
+                    else if (gtail == 2) bwd_tile<2, DROP>(s, dpv, c2, lse2, dl, wq, As, Bs, slot, qt, kh, lane, dKt, dVt);
+                    else bwd_tile<3, DROP>(s, dpv, c2, lse2, dl, wq, As, Bs, slot, qt, kh, lane, dKt, dVt);
                 } else {
-                    bwd_tile<4>(s, dpv, c2, ldl, As, Bs, slot, qt, kh, lane, dKt, dVt);
+                    bwd_tile<4, DROP>(s, dpv, c2, lse2, dl, wq, As, Bs, slot, qt, kh, lane, dKt, dVt);
                 }
             }
-            __syncthreads();                           // staging buffer (qt & 1) is complete; buffer ((qt+1) & 1) has been consumed
+            if (SYNC) {
+                if (active) lds_flag_store(staged + wave, (uint32_t)(qt + 1));      // release: the tile's stores are complete first
+            } else {
+                __syncthreads();                       // staging buffer (qt & 1) is complete; buffer ((qt+1) & 1) has been consumed
+            }
+        };
+        if constexpr (NQT != 0) {
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) step(qt);
+        } else {
+            for (int qt = 0; qt < nqt; ++qt) step(qt);
         }
-        // Q / dO images are dead (every compute wave passed the last barrier): rows [32w, 32w+32) carry this wave's stores
+        // dK / dV leave through this wave's staging slot of the buffer the LAST query tile does not use (tile nqt - 2's: drained
+        // before the last barrier; with flags, wait for it)
         if (active) {
+            if (SYNC && nqt >= 2) {
+                for (int spin = 0; spin < B_SPIN && lds_flag_load(drained) < (uint32_t)(nqt - 1); ++spin) __builtin_amdgcn_s_sleep(1);
+            }
+            char* scr = stg + ((nqt & 1) * CW + wave) * TILE;
             const f32x16 dk1[1] = {dKt}, dv1[1] = {dVt};
-            store_tile_T<32, 1>(As + 32 * wave * RS, RS, dk1, reinterpret_cast<uint16_t*>(d.dk) + (size_t)b * Lk * d.lddk + h * 32, d.lddk,
-                                kt * 32, Lk, lane, osc_dk);
-            store_tile_T<32, 1>(Bs + 32 * wave * RS, RS, dv1, reinterpret_cast<uint16_t*>(d.dv) + (size_t)b * Lk * d.lddv + h * 32, d.lddv,
-                                kt * 32, Lk, lane, 1.f);
+            store_tile_T<32, 1>(scr, TS, dk1, reinterpret_cast<uint16_t*>(d.dk) + (size_t)b * Lk * d.lddk + h * 32, d.lddk, kt * 32, Lk, lane, osc_dk);
+            store_tile_T<32, 1>(scr, TS, dv1, reinterpret_cast<uint16_t*>(d.dv) + (size_t)b * Lk * d.lddv + h * 32, d.lddv, kt * 32, Lk, lane, osc_dv);
         }
     } else {
         // ---------------- wave 7: K^T operands of every key tile, hardware-transposed out of the K image and kept for the
@@ -473,15 +618,24 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
 #pragma unroll
         for (int kt = 0; kt < CW; ++kt)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) kT[kt][s2] = trfrag(stg, RS, min(kt, nkt - 1) * 32 + 16 * s2, 0, lane);
+            for (int s2 = 0; s2 < 2; ++s2) kT[kt][s2] = trfrag_sw(stg, min(kt, nkt - 1) * 32 + 16 * s2, lane);
         __syncthreads();
         uint16_t* dqg = reinterpret_cast<uint16_t*>(d.dq) + (size_t)b * Lq * d.lddq + h * 32;
-        for (int qt = 0; qt < nqt; ++qt) {
-            __syncthreads();
+        auto step = [&](int qt) {
+            if (SYNC) {
+                // every active compute wave has staged tile qt (lanes 0..6 read one word each)
+                for (int spin = 0; spin < B_SPIN; ++spin) {
+                    const uint32_t v = lane < nkt ? lds_flag_load(staged + lane) : 0xffffffffu;
+                    if (__all(v >= (uint32_t)(qt + 1))) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            } else {
+                __syncthreads();
+            }
+            const char* buf = stg + (qt & 1) * CW * TILE;
             f32x16 dQt[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) dQt[0][r] = 0.f;
-            const char* buf = stg + (qt & 1) * CW * TILE;
 #pragma unroll
             for (int kt = 0; kt < CW; ++kt) {
                 if (kt < nkt) {
@@ -490,81 +644,106 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
                         dQt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[kt][s2], trfrag(buf + kt * TILE, TS, 16 * s2, 0, lane), dQt[0], 0, 0, 0);
                 }
             }
-            store_tile_T<32, 1>(sc7, RS, dQt, dqg, d.lddq, qt * 32, Lq, lane, osc_dk);
+            if (SYNC) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every operand read has returned: the slot may be overwritten
+                if (lane == 0) lds_flag_store(drained, (uint32_t)(qt + 1));
+            }
+            store_tile_T<32, 1>(sc7, B_QRS, dQt, dqg, d.lddq, qt * 32, Lq, lane, osc_dk);
+        };
+        if constexpr (NQT != 0) {
+#pragma unroll
+            for (int qt = 0; qt < NQT; ++qt) step(qt);
+        } else {
+            for (int qt = 0; qt < nqt; ++qt) step(qt);
         }
     }
 }
 
 size_t bwd_fast_lds(int Lq, int Lk) {
     const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31;
-    return (size_t)2 * LqP * B_RS + (size_t)2 * LqP * 4 + (size_t)LkP * 4 + (size_t)2 * B_CW * B_TILE + (size_t)32 * B_RS + 64;
-}
-
-int opt_in(const void* kern, size_t bytes) {
-    static std::mutex mu;
-    static std::unordered_map<uint64_t, bool> done;
-    if (bytes <= 65536) return 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const uint64_t key = (uint64_t)(uintptr_t)kern ^ ((uint64_t)(dev + 1) << 56);
-    std::lock_guard<std::mutex> g(mu);
-    if (done.count(key)) return 0;
-    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return mmfm_set_error((int)e, "hipFuncSetAttribute(%zu B LDS): %s", bytes, hipGetErrorString(e));
-    done[key] = true;
-    return 0;
+    return (size_t)2 * LqP * B_RS + (size_t)2 * LqP * 4 + (size_t)LkP * 4 + (size_t)2 * B_CW * B_TILE + (size_t)32 * B_QRS + 128;
 }
 
 }  // namespace
 
-#ifdef MMFM_ATTN_STAMP
-extern "C" int mmfm_attn_probe_read(unsigned long long* host6, int reset) {
-    static unsigned long long* h = new unsigned long long[APROBE_ROWS * 6];
-    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(mmfm_attn_probe_acc), sizeof(unsigned long long) * APROBE_ROWS * 6);
-    for (int i = 0; i < 6; ++i) host6[i] = 0;
-    for (int r = 0; r < APROBE_ROWS; ++r) for (int i = 0; i < 6; ++i) host6[i] += h[r * 6 + i];
-    if (reset) { for (int i = 0; i < APROBE_ROWS * 6; ++i) h[i] = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(mmfm_attn_probe_acc), h, sizeof(unsigned long long) * APROBE_ROWS * 6); }
-    return 0;
+// keep probability the keep-bit path applies for a requested drop probability p (quantised to 2^-KEEP_BITS)
+static uint32_t keep_thresh(float p) {
+    const int one = 1 << KEEP_BITS;
+    const int t = (int)lrintf((1.f - p) * (float)one);
+    return (uint32_t)std::min(std::max(t, 1), one - 1);
 }
-#endif
+extern "C" float mmfm_attn_keep_prob(float p) { return p <= 0.f ? 1.f : (float)keep_thresh(p) / (float)(1 << KEEP_BITS); }
+extern "C" int64_t mmfm_attn_keepbits_bytes(int B, int heads, int Lq, int Lk) {
+    return (int64_t)B * heads * ((Lq + 31) / 32) * ((Lk + 31) / 32) * 128;
+}
 
 // Shapes the fast kernels take.  Returns -1000 when the general kernels must run.
 int mmfm_attn_fast_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st) {
     static const bool off = [] { const char* e = getenv("MMFM_ATTN_FAST"); return e && atoi(e) == 0; }();
+    const int sync_env = [] { const char* e = getenv("MMFM_ATTN_BWD_FLAGS"); return e ? atoi(e) : 1; }();     // per call: a test A/Bs it
     if (off || d.dh != 32 || (d.flags & (MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP))) return -1000;
     const int nqt = (d.Lq + 31) / 32, nkt = (d.Lk + 31) / 32;
     if (d.Lq % 8 || d.Lk % 8 || nqt > 8 || nkt > B_CW || nkt > nqt) return -1000;
     const bool drop = d.drop_p.p > 0.f && d.drop_p.state != nullptr;
     if (drop && d.drop_p.p >= 1.f) return -1000;
+    // with attention dropout the pair needs the keep-bit workspace (one decision source for both directions); without it the general
+    // kernels hash, forward and backward alike
+    if (drop && d.keepbits == nullptr) return -1000;
     const bool al = d.ldq % 8 == 0 && d.ldk % 8 == 0 && d.ldv % 8 == 0 && d.ldo % 8 == 0 && (uintptr_t)d.q % 16 == 0 &&
-                    (uintptr_t)d.k % 16 == 0 && (uintptr_t)d.v % 16 == 0 && (uintptr_t)d.o % 16 == 0;
+                    (uintptr_t)d.k % 16 == 0 && (uintptr_t)d.v % 16 == 0 && (uintptr_t)d.o % 16 == 0 && (uintptr_t)d.keepbits % 128 == 0;
+    if (!al) return -1000;
     const bool alb = !backward || (d.lddo % 8 == 0 && d.lddq % 8 == 0 && d.lddk % 8 == 0 && d.lddv % 8 == 0 && (uintptr_t)d.d_o % 16 == 0 &&
                                    (uintptr_t)d.dq % 16 == 0 && (uintptr_t)d.dk % 16 == 0 && (uintptr_t)d.dv % 16 == 0);
-    if (!al) return -1000;
-    // every untiled bf16 kernel takes the same dropout decisions (attn_common.h Drop16), so the two directions are picked
-    // independently: with attention dropout the backward is the general single-pass kernel (its hash evaluation shares the work
-    // between neighbouring key lanes; ported here it spilled, and the int8-MFMA alternative measured 6 % slower in the step)
-    if (backward && (drop || !alb)) return -1000;
+    if (!alb) {
+        // the forward of this shape took its decisions from the keep bits; the general backward would hash different ones
+        if (drop) return mmfm_set_error(-1, "mmfm_attn_bwd(bf16, dh 32): gradient tensors must be 16-byte aligned with leading dims %% 8 == 0 when "
+                                            "attention dropout runs on the keep-bit path (mmfm_attn_desc.keepbits)");
+        return -1000;
+    }
     const int grid = d.B * d.heads;
+    const float keep_scale = drop ? 1.f / mmfm_attn_keep_prob(d.drop_p.p) : 1.f;
     if (!backward) {
+        if (drop) {
+            KeepArgs a;
+            a.bits = reinterpret_cast<uint32_t*>(d.keepbits);
+            a.state = reinterpret_cast<const uint32_t*>(d.drop_p.state);
+            a.site = d.drop_p.site;
+            a.thresh = keep_thresh(d.drop_p.p);
+            a.nwords = (uint32_t)(mmfm_attn_keepbits_bytes(d.B, d.heads, d.Lq, d.Lk) / 4);
+            hipLaunchKernelGGL(attn_keepbits_kernel, dim3((a.nwords + 255) / 256), dim3(256), 0, st, a);
+            MMFM_LAUNCH_CHECK("mmfm_attn_fwd(keep bits)");
+        }
         const int nw = nqt <= 4 ? 4 : (nqt == 7 ? 7 : (nqt <= 6 ? 6 : 8));
         const size_t lds = fwd_fast_lds(d.Lk, nw);
+#define FWDF3(NWV, DRP, NKT)                                                                                        \
+        {                                                                                                           \
+            auto kern = attn_fwd_fast_kernel<NWV, DRP, NKT>;                                                        \
+            if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(kern), lds, "mmfm_attn_fwd(bf16, dh 32)")) return rc; \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, d, keep_scale);                           \
+        }
 #define FWDF(NWV)                                                                                                   \
         {                                                                                                           \
-            if (drop) { auto kern = attn_fwd_fast_kernel<NWV, true>; if (int rc = opt_in(reinterpret_cast<const void*>(kern), lds)) return rc; \
-                        hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, d); }                         \
-            else { auto kern = attn_fwd_fast_kernel<NWV, false>; if (int rc = opt_in(reinterpret_cast<const void*>(kern), lds)) return rc; \
-                   hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, d); }                              \
+            if (drop) { if (nkt == 7 && NWV >= 7) FWDF3(NWV, true, 7) else FWDF3(NWV, true, 0) }                    \
+            else { if (nkt == 7 && NWV >= 7) FWDF3(NWV, false, 7) else FWDF3(NWV, false, 0) }                       \
         }
         if (nw == 4) FWDF(4) else if (nw == 6) FWDF(6) else if (nw == 7) FWDF(7) else FWDF(8)
 #undef FWDF
+#undef FWDF3
         MMFM_LAUNCH_CHECK("mmfm_attn_fwd(bf16, dh 32)");
         return 0;
     }
-    const size_t lds = bwd_fast_lds(d.Lq, d.Lk);
-    auto kern = attn_bwd_fast_kernel;
-    if (int rc = opt_in(reinterpret_cast<const void*>(kern), lds)) return rc;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(B_NW * 64), lds, st, d);
+    const size_t lds = nqt == 7 ? bwd_fast_lds(224, 224) : bwd_fast_lds(d.Lq, d.Lk);
+#define BWDF3(DRP, SY, NQ)                                                                                          \
+    {                                                                                                               \
+        auto kern = attn_bwd_fast_kernel<DRP, SY, NQ>;                                                              \
+        if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(kern), lds, "mmfm_attn_bwd(bf16, dh 32)")) return rc; \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(B_NW * 64), lds, st, d, keep_scale);                              \
+    }
+#define BWDF(DRP, SY) { if (nqt == 7) BWDF3(DRP, SY, 7) else BWDF3(DRP, SY, 0) }
+    if (drop) { if (sync_env) BWDF(true, 1) else BWDF(true, 0) }
+    else { if (sync_env) BWDF(false, 1) else BWDF(false, 0) }
+#undef BWDF
+#undef BWDF3
     MMFM_LAUNCH_CHECK("mmfm_attn_bwd(bf16, dh 32)");
     return 0;
 }

@@ -556,14 +556,19 @@ class Engine:
         es = 4 if self.dtype == "fp32" else 2
         scale = 1.0 / math.sqrt(dh)
 
+        # keep decisions of the attention-probability dropout: one bit tile set per attention site, written by the forward (generator
+        # kernel in front of it), read by the backward (csrc/attention_fast.hip; 51 MB per site at B = 1024).  MMFM_ATTN_KEEPBITS=0: hash.
+        use_keep = self.code == L.BF16 and dp > 0 and grad and os.environ.get("MMFM_ATTN_KEEPBITS", "1") != "0"
+
         def attn_desc(tag, q, ldq, kv, ldkv, koff, voff, o, flags, d_o=None, dq=None, dkv=None, lddq=0, lddkv=0, dkoff=0, dvoff=0):
+            keep = buf(tag + "/keep", (K.attn_keepbits_bytes(B, heads, Lq, Lq),), u8) if use_keep else None
             return K.attn_desc(code, B, heads, Lq, Lq, dh, q.data_ptr(), kv.data_ptr() + koff * es, kv.data_ptr() + voff * es, ldq, ldkv, ldkv,
                                o.data_ptr(), H, buf(tag + "/lse", (B, heads, Lq), f32), keypad, mod_id, flags, scale,
                                drop_p=self._drop(tag + "/p", dp), drop_o=self._drop(tag + "/o", dp),
                                d_o=None if d_o is None else d_o.data_ptr(), lddo=H,
                                dq=None if dq is None else dq.data_ptr(),
                                dk=None if dkv is None else dkv.data_ptr() + dkoff * es,
-                               dv=None if dkv is None else dkv.data_ptr() + dvoff * es, lddq=lddq, lddk=lddkv, lddv=lddkv)
+                               dv=None if dkv is None else dkv.data_ptr() + dvoff * es, lddq=lddq, lddk=lddkv, lddv=lddkv, keepbits=keep)
 
         fm = self._fused_mask(R)
         F_QKV, F_LNL, F_MLP, F_OUT = bool(fm & 1), bool(fm & 2), bool(fm & 4), bool(fm & 8)

@@ -106,7 +106,9 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, R, H, ws, a
 
 
 def attn_desc(dtype, B, heads, Lq, Lk, dh, q, k, v, ldq, ldk, ldv, o, ldo, lse, keypad, mod_id, flags, scale,
-              drop_p=None, drop_o=None, d_o=None, lddo=0, dq=None, dk=None, dv=None, lddq=0, lddk=0, lddv=0):
+              drop_p=None, drop_o=None, d_o=None, lddo=0, dq=None, dk=None, dv=None, lddq=0, lddk=0, lddv=0, keepbits=None):
+    """keepbits: uint8 tensor of attn_keepbits_bytes(B, heads, Lq, Lk) bytes (one per attention site: the forward writes the keep
+    decisions of drop_p there, the backward reads them) or None (both directions hash; include/mmfm.h)."""
     d = L.AttnDesc()
     d.dtype, d.B, d.heads, d.Lq, d.Lk, d.dh = dtype, B, heads, Lq, Lk, dh
     d.q, d.k, d.v, d.ldq, d.ldk, d.ldv = q, k, v, ldq, ldk, ldv
@@ -114,7 +116,17 @@ def attn_desc(dtype, B, heads, Lq, Lk, dh, q, k, v, ldq, ldk, ldv, o, ldo, lse, 
     d.drop_p = drop_p if drop_p is not None else L.NO_DROP
     d.drop_o = drop_o if drop_o is not None else L.NO_DROP
     d.d_o, d.lddo, d.dq, d.dk, d.dv, d.lddq, d.lddk, d.lddv = d_o, lddo, dq, dk, dv, lddq, lddk, lddv
+    d.keepbits = P(keepbits)
     return d
+
+
+def attn_keepbits_bytes(B, heads, Lq, Lk):
+    return int(L.lib().mmfm_attn_keepbits_bytes(B, heads, Lq, Lk))
+
+
+def attn_keep_prob(p):
+    """Keep probability the keep-bit attention path applies for drop probability p (quantised to 2^-10)."""
+    return float(L.lib().mmfm_attn_keep_prob(float(p)))
 
 
 def attn_fwd(desc, plan=None):

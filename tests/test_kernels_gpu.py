@@ -1,6 +1,7 @@
 """Per-kernel parity: every C-ABI entry point against a plain torch fp32 reference of the same op
 (the oracle's functions where one exists).  Runs on the MI355X only."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -714,6 +715,7 @@ def _extract_attn_keep_mask(ops, state, site, p, B, heads, Lq, Lk):
     q = torch.zeros(B * Lq, H, device="cuda", dtype=torch.bfloat16)
     kp = torch.ones(B, Lk, dtype=torch.uint8, device="cuda")
     keep = torch.zeros(B, heads, Lq, Lk, dtype=torch.bool, device="cuda")
+    kb = torch.empty(ops.attn_keepbits_bytes(B, heads, Lq, Lk), dtype=torch.uint8, device="cuda")
     for blk in range((Lk + 31) // 32):
         kv = torch.zeros(B, Lk, 2, heads, dh, device="cuda", dtype=torch.bfloat16)
         n = min(32, Lk - 32 * blk)
@@ -721,10 +723,25 @@ def _extract_attn_keep_mask(ops, state, site, p, B, heads, Lq, Lk):
         kv = kv.view(B * Lk, 2 * H)
         o, lse = torch.empty(B * Lq, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, Lq, device="cuda")
         desc = ops.attn_desc(Lb.BF16, B, heads, Lq, Lk, dh, q.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * 2, H, 2 * H, 2 * H, o.data_ptr(), H, lse,
-                             kp, None, 0, dh ** -0.5, drop_p=ops.dropout(state, site, p))
+                             kp, None, 0, dh ** -0.5, drop_p=ops.dropout(state, site, p), keepbits=kb)
         ops.attn_fwd(desc)
         keep[:, :, :, 32 * blk:32 * blk + n] = (o.view(B, Lq, heads, dh).permute(0, 2, 1, 3)[..., :n] != 0)
     return keep
+
+
+def _unpack_keepbits(kb, B, heads, Lq, Lk):
+    """keep[b, h, q, k] out of the documented bit-tile layout (csrc/attention_fast.hip header): words [bh][qt][kt][32], word 2 r + kh
+    of a tile = key 32 kt + (r & 3) + 8 (r >> 2) + 4 kh, bit j = query 32 qt + j."""
+    nqt, nkt = (Lq + 31) // 32, (Lk + 31) // 32
+    w = kb.view(torch.int32).view(B * heads, nqt, nkt, 32).cpu().numpy().astype(np.uint32)
+    bits = ((w[..., None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool)          # [bh, qt, kt, word, qbit]
+    widx = np.arange(32)
+    key_of_word = ((widx >> 1) & 3) + 8 * (widx >> 3) + 4 * (widx & 1)
+    keep = np.zeros((B * heads, nqt * 32, nkt * 32), dtype=bool)
+    for qt in range(nqt):
+        for kt in range(nkt):
+            keep[:, 32 * qt:32 * qt + 32, 32 * kt + key_of_word] = bits[:, qt, kt].transpose(0, 2, 1)
+    return torch.from_numpy(keep[:, :Lq, :Lk]).view(B, heads, Lq, Lk)
 
 
 @pytest.mark.parametrize("B,heads,Lq,Lk,flags,pad", [(2, 8, 200, 200, 1, True), (2, 8, 200, 200, 0, False), (3, 4, 72, 40, 0, True), (2, 4, 224, 224, 1, False),
@@ -751,14 +768,19 @@ def test_attention_fast_dropout_matches_reference(ops, B, heads, Lq, Lk, flags, 
     state = torch.zeros(2, dtype=torch.int32, device="cuda")
     ops.rng_seed(state, 4321)
     keep = _extract_attn_keep_mask(ops, state, 7, p, B, heads, Lq, Lk)
+    keep_p = ops.attn_keep_prob(p)                       # the keep-bit path honours p to 2^-10 and scales survivors by 1 / keep_p
+    assert abs(keep_p - (1 - p)) <= 2 ** -11
     rate = keep.float().mean().item()
-    assert abs(rate - (1 - p)) < 5 * math.sqrt(p * (1 - p) / keep.numel()) + 1e-4, f"keep rate {rate}"
+    assert abs(rate - keep_p) < 5 * math.sqrt(p * (1 - p) / keep.numel()) + 1e-4, f"keep rate {rate}"
     o, lse = torch.empty(B * Lq, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, Lq, device="cuda")
     dq, dkv = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
+    kb = torch.empty(ops.attn_keepbits_bytes(B, heads, Lq, Lk), dtype=torch.uint8, device="cuda")
     desc = ops.attn_desc(Lb.BF16, B, heads, Lq, Lk, dh, q.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * 2, H, 2 * H, 2 * H, o.data_ptr(), H, lse,
                          kp, None, flags, dh ** -0.5, drop_p=ops.dropout(state, 7, p), d_o=d_o.data_ptr(), lddo=H, dq=dq.data_ptr(),
-                         dk=dkv.data_ptr(), dv=dkv.data_ptr() + H * 2, lddq=H, lddk=2 * H, lddv=2 * H)
+                         dk=dkv.data_ptr(), dv=dkv.data_ptr() + H * 2, lddq=H, lddk=2 * H, lddv=2 * H, keepbits=kb)
     ops.attn_fwd(desc)
+    # the bit tiles the forward left for the backward are the decisions the forward itself applied (documented layout)
+    assert torch.equal(_unpack_keepbits(kb, B, heads, Lq, Lk), keep.cpu())
     ops.attn_bwd(desc)
     m = kp.bool()[:, None, :].expand(B, Lq, Lk)
     if flags & 1:
@@ -769,13 +791,60 @@ def test_attention_fast_dropout_matches_reference(ops, B, heads, Lq, Lk, flags, 
     s = (Q @ K_.transpose(-1, -2)) * dh ** -0.5
     s = s.masked_fill(~m[:, None], float("-inf"))
     P = torch.softmax(s, -1)
-    oref = ((P * keep.float() / (1 - p)) @ V_).transpose(1, 2).reshape(B * Lq, H)
+    oref = ((P * keep.float() / keep_p) @ V_).transpose(1, 2).reshape(B * Lq, H)
     close_bf16(o, oref, "fast attn fwd with dropout", tol=2e-2)
     close(lse, torch.logsumexp(s, -1), rtol=1e-3, atol=2e-3, msg="fast attn lse")
     oref.backward(d_o.float())
     close_bf16(dq, qr.grad, "fast attn dq", tol=3e-2)
     close_bf16(dkv[:, :H], kvr.grad[:, :H], "fast attn dk", tol=3e-2)
     close_bf16(dkv[:, H:], kvr.grad[:, H:], "fast attn dv", tol=3e-2)
+    # the flag hand-off between the compute waves and the dQ wave (default) against the workgroup-barrier form: same fixed summation
+    # order, bit-identical gradients
+    dq2, dkv2 = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
+    desc.dq, desc.dk, desc.dv = dq2.data_ptr(), dkv2.data_ptr(), dkv2.data_ptr() + H * 2
+    os.environ["MMFM_ATTN_BWD_FLAGS"] = "0"
+    try:
+        ops.attn_bwd(desc)
+    finally:
+        del os.environ["MMFM_ATTN_BWD_FLAGS"]
+    assert torch.equal(dq2, dq) and torch.equal(dkv2, dkv)
+
+
+def test_attention_fast_exact_pass_on_large_scores(ops):
+    """The fast forward keeps the first key tile's row maximum as the reference exponent for the whole row (no running maximum); a
+    row whose later scores overflow against it must come out of the exact pass instead.  Keys 32.. carry 40x larger rows than the
+    first 32 (scores ~ +-500 against ~ +-12), one head's first tile is fully padded: LSE, output and gradients against torch fp32."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    B, heads, L, dh = 2, 4, 200, 32
+    H = heads * dh
+    q = bf(rnd(B * L, H, seed=11) * 2.0)
+    kv = rnd(B * L, 2 * H, seed=12)
+    kv.view(B, L, 2 * H)[:, 32:, :H] *= 40.0
+    kv = bf(kv)
+    d_o = bf(rnd(B * L, H, seed=13))
+    kp = torch.ones(B, L, dtype=torch.uint8)
+    kp[1, :32] = 0
+    kp = kp.cuda()
+    o, lse = torch.empty(B * L, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, L, device="cuda")
+    dq, dkv = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
+    desc = ops.attn_desc(Lb.BF16, B, heads, L, L, dh, q.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * 2, H, 2 * H, 2 * H, o.data_ptr(), H, lse,
+                         kp, None, 0, dh ** -0.5, d_o=d_o.data_ptr(), lddo=H, dq=dq.data_ptr(), dk=dkv.data_ptr(), dv=dkv.data_ptr() + H * 2,
+                         lddq=H, lddk=2 * H, lddv=2 * H)
+    ops.attn_fwd(desc)
+    ops.attn_bwd(desc)
+    qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    Q = qr.view(B, L, heads, dh).transpose(1, 2)
+    K_, V_ = [t.view(B, L, heads, dh).transpose(1, 2) for t in kvr.split(H, dim=1)]
+    s = (Q @ K_.transpose(-1, -2)) * dh ** -0.5
+    assert s.max().item() > 150                                        # beyond 2^100 against a first-tile reference
+    s = s.masked_fill(~kp.bool()[:, None, None, :], float("-inf"))
+    oref = (torch.softmax(s, -1) @ V_).transpose(1, 2).reshape(B * L, H)
+    close_bf16(o, oref, "exact-pass fwd", tol=2e-2)
+    close(lse, torch.logsumexp(s, -1), rtol=1e-3, atol=2e-2, msg="exact-pass lse")
+    oref.backward(d_o.float())
+    close_bf16(dq, qr.grad, "exact-pass dq", tol=3e-2)
+    close_bf16(dkv[:, :H], kvr.grad[:, :H], "exact-pass dk", tol=3e-2)
+    close_bf16(dkv[:, H:], kvr.grad[:, H:], "exact-pass dv", tol=3e-2)
 
 
 def test_attention_fast_dropout_statistics(ops):
@@ -786,18 +855,19 @@ def test_attention_fast_dropout_statistics(ops):
     ops.rng_seed(state, 77)
     k = _extract_attn_keep_mask(ops, state, 3, p, B, heads, L, L).float()
     var = p * (1 - p)
-    assert abs(k.mean().item() - (1 - p)) < 4 * math.sqrt(var / k.numel())
-    c = k - (1 - p)
+    keep_p = ops.attn_keep_prob(p)
+    assert abs(k.mean().item() - keep_p) < 4 * math.sqrt(var / k.numel())
+    c = k - keep_p
     corr = lambda a, b: (a * b).mean().item() / var
-    assert abs(corr(c[..., 0::2], c[..., 1::2])) < 0.01                                   # the two keys of one hash
+    assert abs(corr(c[..., 0::2], c[..., 1::2])) < 0.01                                   # neighbouring keys
     for lag in (1, 2, 16, 32):
         assert abs(corr(c[:, :, :-lag], c[:, :, lag:])) < 0.01, f"query lag {lag}"
         assert abs(corr(c[:, :, :, :-lag], c[:, :, :, lag:])) < 0.01, f"key lag {lag}"
     assert abs(corr(c[:, :-1], c[:, 1:])) < 0.01 and abs(corr(c[:-1], c[1:])) < 0.01      # heads, samples
-    assert abs(corr(c, _extract_attn_keep_mask(ops, state, 4, p, B, heads, L, L).float() - (1 - p))) < 0.01          # another site
+    assert abs(corr(c, _extract_attn_keep_mask(ops, state, 4, p, B, heads, L, L).float() - keep_p)) < 0.01          # another site
     assert torch.equal(k, _extract_attn_keep_mask(ops, state, 3, p, B, heads, L, L).float())
     ops.rng_advance(state)
-    assert abs(corr(c, _extract_attn_keep_mask(ops, state, 3, p, B, heads, L, L).float() - (1 - p))) < 0.01          # next step
+    assert abs(corr(c, _extract_attn_keep_mask(ops, state, 3, p, B, heads, L, L).float() - keep_p)) < 0.01          # next step
 
 
 @pytest.mark.parametrize("M,N,K,kc", [(204800 + 37, 768, 256, 1), (204800 + 37, 256, 768, 0), (204800, 512, 256, 1)])
