@@ -60,10 +60,14 @@ struct KeepArgs {
     const uint32_t* state;
     uint32_t site, thresh;        // thresh = round(keep * 2^KEEP_BITS) in [1, 2^KEEP_BITS - 1]
     uint32_t nwords;
+    int nkt, Lk;
 };
 __global__ __launch_bounds__(256) void attn_keepbits_kernel(const KeepArgs a) {
     const uint32_t gid = blockIdx.x * 256u + threadIdx.x;
     if (gid >= a.nwords) return;
+    // words of keys beyond the head's last key (the padded part of the last key tile) are never looked at: 11 % of them at L = 200
+    const uint32_t w = gid & 31u, kt = (gid >> 5) % (uint32_t)a.nkt;
+    if ((int)(32u * kt + ((w >> 1) & 3u) + 8u * (w >> 3) + 4u * (w & 1u)) >= a.Lk) return;
     const uint32_t k0 = mix32(a.state[0] + a.site * 0x9E3779B9u), k1 = mix32(a.state[1] ^ (a.site * 0x85EBCA6Bu + 0xC2B2AE35u));
     const uint32_t s = mix32(gid ^ k0);
     const uint32_t kb = k1 + __umul24(s >> 24, 0x9E3779u);       // v_mul_u32_u24 sees bits 0..23 only: the top byte enters here
@@ -73,7 +77,7 @@ __global__ __launch_bounds__(256) void attn_keepbits_kernel(const KeepArgs a) {
         if ((a.thresh & ((2u << j) - 1u)) == 0) continue;        // trailing zero digits leave r = 0 (uniform branch)
         uint32_t h = __umul24(s + (uint32_t)j * 0x3C6EF35Fu, 0x7FEB35u) + kb;
         h ^= h >> 13;
-        h = __umul24(h, 0x46CA6Bu) ^ (h >> 9);
+        h = __umul24(h, 0x46CA6Bu);
         h ^= h >> 16;
         r = ((a.thresh >> j) & 1u) ? (h | r) : (h & r);
     }
@@ -344,11 +348,10 @@ size_t fwd_fast_lds(int Lk, int nw) {
 //     SQ_LDS_IDX_ACTIVE);
 //   * dropout decisions come from the forward's keep bits: a lane (= key) loads its word of every query tile with the prologue
 //     loads (<= 8 dwords) and expands one bit per element (v_bfe_i32 -> and);
-//   * SYNC = 1: no workgroup barrier in the query-tile loop.  A compute wave publishes "tile qt staged" in its own LDS word and
-//     only waits for wave 7 to have drained the slot it is about to overwrite (two steps back), wave 7 waits for the seven words:
-//     the compute waves no longer run in lock step (they contend for the same pipe at the same time when they do).
+//   * tried and removed: an LDS-flag hand-off in place of the per-tile workgroup barrier (a compute wave publishes "tile qt staged" in
+//     its own word and only waits for wave 7 to have drained the slot it overwrites, wave 7 waits for the seven words) so that the
+//     compute waves need not run in lock step: bit-identical results, 2-3 % SLOWER on two boxes (339 / 335 us against 332 / 324).
 constexpr int B_NW = 8, B_CW = 7, B_TS = 80, B_TILE = 32 * B_TS, B_RS = 64, B_QRS = 80;
-constexpr int B_SPIN = 1 << 22;                      // bound of every flag wait: a lost hand-off ends in wrong numbers, never in a hang
 
 __device__ __forceinline__ int img_off(int row, int chunk) { return row * B_RS + ((chunk ^ ((row >> 2) & 3)) << 4); }
 // transposed operand out of a swizzled dense image: element j = image[rbase + 8 (j >> 2) + 4 h + (j & 3)][c]   (rbase % 16 == 0)
@@ -361,13 +364,6 @@ __device__ __forceinline__ bf16x8v trfrag_sw(const char* S, int rbase, int lane)
     s16x8 v;
     v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
     return __builtin_bit_cast(bf16x8v, v);
-}
-
-__device__ __forceinline__ uint32_t lds_flag_load(const uint32_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void lds_flag_store(uint32_t* p, uint32_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // one query tile of a compute wave (lane = key, rows = queries).  GRP = 8-query groups of the tile that exist (registers 4g .. 4g+3 =
@@ -420,7 +416,7 @@ __device__ __forceinline__ void bwd_tile(const f32x16& s, const f32x16& dpv, flo
 
 // NQT = query tiles of the head when known at compile time (7: the L = 200 / 224 step shapes - the query-tile loop is then straight-line
 // code and every LDS address in it a lane constant plus an immediate), 0 = read from the descriptor.
-template <bool DROP, int SYNC, int NQT>
+template <bool DROP, int NQT>
 __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_attn_desc d, const float keep_scale) {
     constexpr int NW = B_NW, CW = B_CW, TS = B_TS, TILE = B_TILE, RS = B_RS, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -437,7 +433,7 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
     float* kbias = dl + LqP;
     char* stg = reinterpret_cast<char*>(kbias + LkP); // [2][CW][32 keys x TS] dS^T tiles; first the K image (prologue only)
     char* sc7 = stg + 2 * CW * TILE;                  // [32 x B_QRS] dQ transpose tile of wave 7
-    uint32_t* flags = reinterpret_cast<uint32_t*>(sc7 + 32 * B_QRS);      // [0..7]: pad votes; [8..15]: staged[w]; [16]: drained
+    uint32_t* flags = reinterpret_cast<uint32_t*>(sc7 + 32 * B_QRS);      // [0..7]: per-wave pad votes
     const uint16_t* qg = reinterpret_cast<const uint16_t*>(d.q) + (size_t)b * Lq * d.ldq + h * 32;
     const uint16_t* kg = reinterpret_cast<const uint16_t*>(d.k) + (size_t)b * Lk * d.ldk + h * 32;
     const uint16_t* vg = reinterpret_cast<const uint16_t*>(d.v) + (size_t)b * Lk * d.ldv + h * 32;
@@ -519,8 +515,6 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
     for (int w = 0; w < NW; ++w) anypad |= (int)flags[w];
     anypad = __builtin_amdgcn_readfirstlane(anypad);
     const float c2 = d.scale * LOG2E;
-    uint32_t* staged = flags + 8;                     // staged[w] = query tiles wave w has staged
-    uint32_t* drained = flags + 16;                   // query tiles wave 7 has drained
 
     if (wave < CW) {
         // ---------------- compute waves: one key tile each, all query tiles
@@ -564,9 +558,6 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
             }
         };
         const int gtail = ((Lq - (nqt - 1) * 32) + 7) >> 3;            // valid 8-query groups of the last query tile (Lq % 8 == 0)
-        if (SYNC) {
-            if (lane == 0) { staged[wave] = 0u; if (wave == 0) *drained = 0u; }
-        }
         __syncthreads();                               // wave 7 has its K^T operands: the K image is dead, the staging slots free
         auto step = [&](int qt) {
             if (active) {
@@ -575,9 +566,6 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
                 if (DROP) {
                     wq = kw_next >> (4 * kh);          // bit (r & 3) + 8 (r >> 2) is now register r's query
                     kw_next = kbp[(size_t)min(qt + 1, nqt - 1) * kw_stride];
-                }
-                if (SYNC && qt >= 2) {                 // the slot still holds tile qt - 2 until wave 7 has its operands
-                    for (int spin = 0; spin < B_SPIN && lds_flag_load(drained) < (uint32_t)(qt - 1); ++spin) __builtin_amdgcn_s_sleep(1);
                 }
                 char* slot = stg + ((qt & 1) * CW + wave) * TILE + l31 * TS;
                 if (qt == nqt - 1 && gtail != 4) {
@@ -588,11 +576,7 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
                     bwd_tile<4, DROP>(s, dpv, c2, lse2, dl, wq, As, Bs, slot, qt, kh, lane, dKt, dVt);
                 }
             }
-            if (SYNC) {
-                if (active) lds_flag_store(staged + wave, (uint32_t)(qt + 1));      // release: the tile's stores are complete first
-            } else {
-                __syncthreads();                       // staging buffer (qt & 1) is complete; buffer ((qt+1) & 1) has been consumed
-            }
+            __syncthreads();                           // staging buffer (qt & 1) is complete; buffer ((qt+1) & 1) has been consumed
         };
         if constexpr (NQT != 0) {
 #pragma unroll
@@ -601,11 +585,8 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
             for (int qt = 0; qt < nqt; ++qt) step(qt);
         }
         // dK / dV leave through this wave's staging slot of the buffer the LAST query tile does not use (tile nqt - 2's: drained
-        // before the last barrier; with flags, wait for it)
+        // before the last barrier)
         if (active) {
-            if (SYNC && nqt >= 2) {
-                for (int spin = 0; spin < B_SPIN && lds_flag_load(drained) < (uint32_t)(nqt - 1); ++spin) __builtin_amdgcn_s_sleep(1);
-            }
             char* scr = stg + ((nqt & 1) * CW + wave) * TILE;
             const f32x16 dk1[1] = {dKt}, dv1[1] = {dVt};
             store_tile_T<32, 1>(scr, TS, dk1, reinterpret_cast<uint16_t*>(d.dk) + (size_t)b * Lk * d.lddk + h * 32, d.lddk, kt * 32, Lk, lane, osc_dk);
@@ -622,16 +603,7 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
         __syncthreads();
         uint16_t* dqg = reinterpret_cast<uint16_t*>(d.dq) + (size_t)b * Lq * d.lddq + h * 32;
         auto step = [&](int qt) {
-            if (SYNC) {
-                // every active compute wave has staged tile qt (lanes 0..6 read one word each)
-                for (int spin = 0; spin < B_SPIN; ++spin) {
-                    const uint32_t v = lane < nkt ? lds_flag_load(staged + lane) : 0xffffffffu;
-                    if (__all(v >= (uint32_t)(qt + 1))) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            } else {
-                __syncthreads();
-            }
+            __syncthreads();
             const char* buf = stg + (qt & 1) * CW * TILE;
             f32x16 dQt[1];
 #pragma unroll
@@ -643,10 +615,6 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
                     for (int s2 = 0; s2 < 2; ++s2)
                         dQt[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kT[kt][s2], trfrag(buf + kt * TILE, TS, 16 * s2, 0, lane), dQt[0], 0, 0, 0);
                 }
-            }
-            if (SYNC) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // every operand read has returned: the slot may be overwritten
-                if (lane == 0) lds_flag_store(drained, (uint32_t)(qt + 1));
             }
             store_tile_T<32, 1>(sc7, B_QRS, dQt, dqg, d.lddq, qt * 32, Lq, lane, osc_dk);
         };
@@ -661,7 +629,7 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
 
 size_t bwd_fast_lds(int Lq, int Lk) {
     const int LqP = (Lq + 31) & ~31, LkP = (Lk + 31) & ~31;
-    return (size_t)2 * LqP * B_RS + (size_t)2 * LqP * 4 + (size_t)LkP * 4 + (size_t)2 * B_CW * B_TILE + (size_t)32 * B_QRS + 128;
+    return (size_t)2 * LqP * B_RS + (size_t)2 * LqP * 4 + (size_t)LkP * 4 + (size_t)2 * B_CW * B_TILE + (size_t)32 * B_QRS + 64;
 }
 
 }  // namespace
@@ -680,7 +648,6 @@ extern "C" int64_t mmfm_attn_keepbits_bytes(int B, int heads, int Lq, int Lk) {
 // Shapes the fast kernels take.  Returns -1000 when the general kernels must run.
 int mmfm_attn_fast_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st) {
     static const bool off = [] { const char* e = getenv("MMFM_ATTN_FAST"); return e && atoi(e) == 0; }();
-    const int sync_env = [] { const char* e = getenv("MMFM_ATTN_BWD_FLAGS"); return e ? atoi(e) : 1; }();     // per call: a test A/Bs it
     if (off || d.dh != 32 || (d.flags & (MMFM_ATTN_CAUSAL | MMFM_ATTN_SEP))) return -1000;
     const int nqt = (d.Lq + 31) / 32, nkt = (d.Lk + 31) / 32;
     if (d.Lq % 8 || d.Lk % 8 || nqt > 8 || nkt > B_CW || nkt > nqt) return -1000;
@@ -710,6 +677,8 @@ int mmfm_attn_fast_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st
             a.site = d.drop_p.site;
             a.thresh = keep_thresh(d.drop_p.p);
             a.nwords = (uint32_t)(mmfm_attn_keepbits_bytes(d.B, d.heads, d.Lq, d.Lk) / 4);
+            a.nkt = nkt;
+            a.Lk = d.Lk;
             hipLaunchKernelGGL(attn_keepbits_kernel, dim3((a.nwords + 255) / 256), dim3(256), 0, st, a);
             MMFM_LAUNCH_CHECK("mmfm_attn_fwd(keep bits)");
         }
@@ -733,16 +702,14 @@ int mmfm_attn_fast_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st
         return 0;
     }
     const size_t lds = nqt == 7 ? bwd_fast_lds(224, 224) : bwd_fast_lds(d.Lq, d.Lk);
-#define BWDF3(DRP, SY, NQ)                                                                                          \
+#define BWDF3(DRP, NQ)                                                                                              \
     {                                                                                                               \
-        auto kern = attn_bwd_fast_kernel<DRP, SY, NQ>;                                                              \
+        auto kern = attn_bwd_fast_kernel<DRP, NQ>;                                                                  \
         if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(kern), lds, "mmfm_attn_bwd(bf16, dh 32)")) return rc; \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(B_NW * 64), lds, st, d, keep_scale);                              \
     }
-#define BWDF(DRP, SY) { if (nqt == 7) BWDF3(DRP, SY, 7) else BWDF3(DRP, SY, 0) }
-    if (drop) { if (sync_env) BWDF(true, 1) else BWDF(true, 0) }
-    else { if (sync_env) BWDF(false, 1) else BWDF(false, 0) }
-#undef BWDF
+    if (drop) { if (nqt == 7) BWDF3(true, 7) else BWDF3(true, 0) }
+    else { if (nqt == 7) BWDF3(false, 7) else BWDF3(false, 0) }
 #undef BWDF3
     MMFM_LAUNCH_CHECK("mmfm_attn_bwd(bf16, dh 32)");
     return 0;

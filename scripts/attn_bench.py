@@ -35,4 +35,4 @@ for fn, name, fl in ((ops.attn_fwd, "fwd", 4.0), (ops.attn_bwd, "bwd", 10.0)):
         fn(desc)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
-    print(f"attn_{name} {dtype} B={B} p={p} keepbits={int(kb is not None)} flags={os.environ.get('MMFM_ATTN_BWD_FLAGS', '1')}: {ms*1e3:.1f} us  {fl*B*heads*L*L*dh/ms/1e9:.1f} TFLOP/s")
+    print(f"attn_{name} {dtype} B={B} p={p} keepbits={int(kb is not None)}: {ms*1e3:.1f} us  {fl*B*heads*L*L*dh/ms/1e9:.1f} TFLOP/s")
