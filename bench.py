@@ -82,34 +82,42 @@ def kernel_profile(engine, plan, reps=3):
     rows = []
     for i, (fn, args, keep) in enumerate(entries):
         ms = acc[i] / reps
-        name, flops, sub = fn.__name__, 0.0, None
+        name, flops, sub, nbytes = fn.__name__, 0.0, None, 0.0          # nbytes = ALGORITHMIC bytes (operands read once + results written once)
         if name == "mmfm_gemm":
             d = keep[0]
             flops = 2.0 * d.M * d.N * d.K
             sub = "x.W^T" if (d.a_kcontig and d.b_kcontig) else ("dY.W" if d.a_kcontig else "dY^T.X")
+            nbytes = 2.0 * (d.M * d.K + d.N * d.K) + (4.0 if d.c_f32 else 2.0) * d.M * d.N * max(1, d.splits)
         elif name == "mmfm_gemm_pair":          # two weight gradients in one launch: one launch of the GEMM family
             name = "mmfm_gemm"
             flops = sum(2.0 * d.M * d.N * d.K for d in keep[:2])
+            nbytes = sum(2.0 * (d.M * d.K + d.N * d.K) + 4.0 * d.M * d.N * max(1, d.splits) for d in keep[:2])
             sub = "dY^T.X"
         elif name == "mmfm_rowgemm":
             d = keep[0]
             flops = 2.0 * d.R * d.N * d.K
             sub = "row dX (+LN bwd)" if d.ln_bwd else ("row LN+x.W^T" if d.ln else ("row x.W^T" if d.bias else "row dY.W"))
+            nbytes = 2.0 * d.R * (d.K + d.N) + 2.0 * d.N * d.K + (2.0 * d.R * d.N if d.residual else 0) + (2.0 * d.R * d.K if d.xhat else 0) \
+                + (2.0 * d.R * d.N if d.ln_bwd else 0)
         elif name in ("mmfm_mlp_fwd", "mmfm_mlp_bwd"):
             d = keep[0]
             flops = 4.0 * d.R * 256 * 512           # algorithmic: two products each way (the backward's recompute of up() is not counted)
             sub = "row MLP fwd" if name.endswith("fwd") else "row MLP bwd (dX chain)"
+            nbytes = 2.0 * d.R * 256 * (3 if name.endswith("fwd") else 4) + (2.0 * d.R * 512 * 2 if name.endswith("bwd") else 0)
         elif name in ("mmfm_attn_fwd", "mmfm_attn_bwd"):
             d = keep[0]
             flops = (4.0 if name.endswith("fwd") else 10.0) * d.B * d.heads * d.Lq * d.Lk * d.dh
-        rows.append((name, ms, flops, sub))
+            hd = d.heads * d.dh
+            nbytes = 2.0 * d.B * hd * ((d.Lq + 2 * d.Lk + d.Lq) if name.endswith("fwd") else (3 * d.Lq + 2 * d.Lk + d.Lq + 2 * d.Lk)) \
+                + (d.B * d.heads * ((d.Lq + 31) // 32) * ((d.Lk + 31) // 32) * 128 * (2 if name.endswith("fwd") else 1) if d.keepbits else 0)
+        rows.append((name, ms, flops, sub, nbytes))
     agg, subs = {}, {}
-    for name, ms, fl, sub in rows:
-        a = agg.setdefault(name, [0, 0.0, 0.0])
-        a[0] += 1; a[1] += ms; a[2] += fl
+    for name, ms, fl, sub, nb in rows:
+        a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+        a[0] += 1; a[1] += ms; a[2] += fl; a[3] += nb
         if sub:
-            b = subs.setdefault(sub, [0, 0.0, 0.0])
-            b[0] += 1; b[1] += ms; b[2] += fl
+            b = subs.setdefault(sub, [0, 0.0, 0.0, 0.0])
+            b[0] += 1; b[1] += ms; b[2] += fl; b[3] += nb
     return agg, subs
 
 
@@ -380,27 +388,76 @@ def main():
             tot = sum(v[1] for v in agg.values())
             top = sorted(agg.items(), key=lambda kv: -kv[1][1])
             res["kernel_breakdown_ms"] = {k: round(v[1], 3) for k, v in top[:8]}
-            res["gemm_layouts"] = {k: dict(launches=v[0], ms=round(v[1], 3), tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1)) for k, v in subs.items()}
+            res["gemm_layouts"] = {k: dict(launches=v[0], ms=round(v[1], 3), tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                                           gbs_algorithmic=round(v[3] / (v[1] * 1e-3) / 1e9, 1)) for k, v in subs.items()}
             res["kernel_time_sum_ms"] = round(tot, 3)
-            # dominant kernel family = the dense linears (every nn.Linear forward / dX / dW product of the step): the generic tiled
-            # GEMM plus the row-owner fused kernels that absorbed LayerNorm / GELU / residual work
-            FAM = ("mmfm_gemm", "mmfm_rowgemm", "mmfm_mlp_fwd", "mmfm_mlp_bwd")
-            fam = [agg[n] for n in FAM if n in agg]
-            v = [sum(x[0] for x in fam), sum(x[1] for x in fam), sum(x[2] for x in fam)]
-            k = "dense linears: " + "+".join(n for n in FAM if n in agg)
-            res["family_ms"] = {n: round(agg[n][1], 3) for n in FAM if n in agg}
-            achieved = v[2] / (v[1] * 1e-3) / 1e12
-            traffic = None
+            # Kernel families of the step, each against the roof that bounds it (arithmetic intensity against the
+            # ridge 2500 TF / 8 TB/s = 312 flop/B decides between MFMA and HBM; attention is bound by vector-instruction issue).
+            # `traffic` = HBM bytes by PMC (profiles/pmc_traffic.json, only when taken on THIS library) where available, else the
+            # algorithmic bytes (operands read once, results written once).
+            tj = None
             tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):                 # only a PMC pass taken on THIS library (same kernel sources) is attached
+            if os.path.exists(tpath):
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("src_sha") == src_sha() and all(n in tj for n in FAM if n in agg):
-                    traffic = int(sum(tj[n] * agg[n][0] for n in FAM if n in agg) / max(1, v[0]))
-            res["roofline"] = dict(bound="mfma", kernel=k, launches_per_step=v[0], achieved=round(achieved, 2),
-                                   peak=PEAK_TFLOPS[a.dtype], unit="TFLOP/s", frac=round(achieved / PEAK_TFLOPS[a.dtype], 4),
-                                   traffic=traffic, avg_launch_ms=round(v[1] / v[0], 4),
-                                   algorithmic_flops_per_launch=v[2] / v[0])
+                if tj.get("src_sha") != src_sha():
+                    tj = None
+            RIDGE = PEAK_TFLOPS[a.dtype] * 1e12 / (HBM_PEAK_GBS * 1e9)
+
+            def family(label, names, sub_names=None, valu_slots=None):
+                if sub_names is not None:
+                    parts = [subs[n] for n in sub_names if n in subs]
+                else:
+                    parts = [agg[n] for n in names if n in agg]
+                if not parts:
+                    return None
+                n, ms, fl, nb = (sum(x[i] for x in parts) for i in range(4))
+                pmc = None
+                if tj is not None and sub_names is None and all(k in tj for k in names if k in agg):
+                    pmc = sum(tj[k] * agg[k][0] for k in names if k in agg)
+                byts = pmc if pmc is not None else nb
+                tf, gbs = fl / (ms * 1e-3) / 1e12, byts / (ms * 1e-3) / 1e9
+                out = dict(family=label, launches_per_step=n, ms_per_step=round(ms, 3), tflops=round(tf, 1), mfma_frac=round(tf / PEAK_TFLOPS[a.dtype], 4),
+                           hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4), bytes_per_launch=int(byts / n),
+                           bytes_source="pmc" if pmc is not None else "algorithmic", flop_per_byte=round(fl / max(byts, 1.0), 1))
+                out["bound"] = "mfma" if fl / max(byts, 1.0) >= RIDGE else "hbm"
+                if valu_slots is not None:
+                    # issue floor: vector issue slots per score element x elements, one slot = 4 cycles of one of the chip's 1,024 SIMDs
+                    floor_ms = valu_slots / (1024 * 2.4e9 / 4) * 1e3
+                    out.update(bound="valu-issue", valu_issue_floor_ms=round(floor_ms, 3), valu_issue_frac=round(floor_ms / ms, 4))
+                return out
+
+            FAM = ("mmfm_gemm", "mmfm_rowgemm", "mmfm_mlp_fwd", "mmfm_mlp_bwd")
+            res["family_ms"] = {n: round(agg[n][1], 3) for n in FAM if n in agg}
+            att_slots = 0.0
+            for fn, args, keep in list(eng._last["fwd"]) + [e for _, seg in eng._last["bwd"] for e in seg]:
+                if fn.__name__ in ("mmfm_attn_fwd", "mmfm_attn_bwd"):
+                    d = keep[0]
+                    # measured instruction mix of the dh = 32 keep-bit kernels (csrc/attention_fast.hip): 6 issue slots per score element in
+                    # the forward (fma, exp x2, add, select, half a pack + the MFMAs' issue share), 9 in the backward; 64 elements per slot
+                    att_slots += (6.0 if fn.__name__.endswith("fwd") else 9.0) * d.B * d.heads * d.Lq * d.Lk / 64.0
+            fams = [family("dense linears (x.W^T, dY.W, row-owner LN / MLP kernels)", FAM, sub_names=[k for k in subs if k != "dY^T.X"]),
+                    family("weight gradients (dY^T.X, streaming split-K)", ("mmfm_gemm",), sub_names=["dY^T.X"]),
+                    family("attention (dh 32 keep-bit kernels)", ("mmfm_attn_fwd", "mmfm_attn_bwd"), valu_slots=att_slots)]
+            res["roofline_families"] = [f for f in fams if f]
+            fam = [agg[n] for n in FAM if n in agg]
+            v = [sum(x[i] for x in fam) for i in range(4)]
+            k = "dense linears: " + "+".join(n for n in FAM if n in agg)
+            traffic = None
+            if tj is not None and all(n in tj for n in FAM if n in agg):
+                traffic = int(sum(tj[n] * agg[n][0] for n in FAM if n in agg) / max(1, v[0]))
+            byts = traffic * v[0] if traffic is not None else v[3]
+            tf, gbs = v[2] / (v[1] * 1e-3) / 1e12, byts / (v[1] * 1e-3) / 1e9
+            hbm_bound = v[2] / max(byts, 1.0) < RIDGE
+            # the dominant family against ITS roof: HBM when its arithmetic intensity sits under the ridge (it does: ~140 flop/B)
+            res["roofline"] = dict(bound="hbm" if hbm_bound else "mfma", kernel=k, launches_per_step=v[0],
+                                   achieved=round(gbs if hbm_bound else tf, 2), peak=HBM_PEAK_GBS if hbm_bound else PEAK_TFLOPS[a.dtype],
+                                   unit="GB/s" if hbm_bound else "TFLOP/s",
+                                   frac=round((gbs / HBM_PEAK_GBS) if hbm_bound else (tf / PEAK_TFLOPS[a.dtype]), 4),
+                                   hbm_frac=round(gbs / HBM_PEAK_GBS, 4), mfma_frac=round(tf / PEAK_TFLOPS[a.dtype], 4),
+                                   traffic=traffic, avg_launch_ms=round(v[1] / v[0], 4), algorithmic_flops_per_launch=v[2] / v[0],
+                                   algorithmic_bytes_per_launch=v[3] / v[0], flop_per_byte=round(v[2] / max(byts, 1.0), 1),
+                                   ridge_flop_per_byte=round(RIDGE, 1))
         if world == 1 and not a.no_extra_legs:
             try:
                 log("extra legs: exact masker stream, fp32 parity mode, multi-session, config 5")

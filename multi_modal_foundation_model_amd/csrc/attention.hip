@@ -833,6 +833,7 @@ int check_common(const mmfm_attn_desc& d, const char* who) {
 
 int mmfm_attn_bf16_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st);   // attention_bf16.hip (bf16 MFMA)
 int mmfm_attn_fast_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st);   // attention_fast.hip (bf16, dh 32, L <= 224)
+int mmfm_attn_long_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st);   // attention_long.hip (bf16, dh 64, keep-bit workspace)
 
 #define ATTN_TILED(KERN, GY, ...)                                                                                  \
     {                                                                                                              \
@@ -875,6 +876,8 @@ extern "C" int mmfm_attn_fwd(const mmfm_attn_desc* dp, mmfm_stream stream) {
     if (d.dtype == MMFM_BF16) {          // bf16 MFMA kernel; shapes it does not take fall through to fp32 compute on bf16 storage
         const int rf = mmfm_attn_fast_launch(d, false, (hipStream_t)stream);
         if (rf != -1000) return rf;
+        const int rl = mmfm_attn_long_launch(d, false, (hipStream_t)stream);
+        if (rl != -1000) return rl;
         const int rc = mmfm_attn_bf16_launch(d, false, (hipStream_t)stream);
         if (rc != -1000) return rc;
     }
@@ -906,6 +909,8 @@ extern "C" int mmfm_attn_bwd(const mmfm_attn_desc* dp, mmfm_stream stream) {
     if (d.dtype == MMFM_BF16) {
         const int rf = mmfm_attn_fast_launch(d, true, (hipStream_t)stream);
         if (rf != -1000) return rf;
+        const int rl = mmfm_attn_long_launch(d, true, (hipStream_t)stream);
+        if (rl != -1000) return rl;
         const int rc = mmfm_attn_bf16_launch(d, true, (hipStream_t)stream);
         if (rc != -1000) return rc;
     }

@@ -29,27 +29,6 @@ namespace {
 
 constexpr int KEEP_BITS = 10;         // the keep probability is honoured to 2^-10 (mmfm_attn_keep_prob)
 
-// ---------------------------------------------------------------------------------------------- helpers
-// NO vector instruction of these kernels lives in inline asm.  Round 4 tried (v_add / v_max3 / v_cndmask / v_bfe in asm, to keep the
-// compiler from packing fp32 pairs or rewriting a bit test): every launch returned garbage.  gfx950 leaves several read-after-write
-// waits to software (an MFMA's result, a transcendental's, a permlane's) and the compiler inserts them only around instructions it
-// can see.  What shapes the code instead: -fno-slp-vectorize for this file (Makefile: v_pk_*_f32 is 8 issue cycles for two results,
-// no gain beside MFMAs), __builtin_amdgcn_inverse_ballot_w64 for "select by a scalar lane mask" (one v_cndmask_b32 with an SGPR pair),
-// and EMPTY asm statements as optimisation barriers only.
-__device__ __forceinline__ float v_max(float a, float b) { return fmaxf(a, b); }
-__device__ __forceinline__ float v_add(float a, float b) { return a + b; }
-__device__ __forceinline__ float v_mul(float a, float b) { return a * b; }
-// p where the lane's bit of `mask` is set, else 0
-__device__ __forceinline__ float v_keep(float p, uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask) ? p : 0.f; }
-__device__ __forceinline__ float xhalf_max(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return v_max(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xhalf_sum(float v) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-
 // ---------------------------------------------------------------------------------------------- keep-bit generator
 // One thread per 32-decision word.  Bernoulli(keep) bits from uniform words by the binary expansion keep = 0.b1 b2 ... bn:
 // walking the bits from the least significant, r = b ? (u | r) : (u & r) halves the distance to the next digit each time, so after
@@ -88,21 +67,6 @@ __global__ __launch_bounds__(256) void attn_keepbits_kernel(const KeepArgs a) {
 // One key tile (32 keys x 32 queries, lane = query): probabilities of the scores `st` (key bias already inside) against the row's
 // reference exponent, dropout, O^T += V^T P^T.  G = 8-key groups of the tile that exist (registers 4g .. 4g+3), mk = the tile's 16
 // lane masks.  nm = -(reference): see the kernel for the two modes.
-struct Masks16 { uint64_t m[16]; };
-typedef const Masks16 __attribute__((address_space(4))) * masks_ptr;      // constant address space: scalar loads
-__device__ __forceinline__ Masks16 ld_masks(masks_ptr p) {
-    Masks16 r;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) r.m[i] = p->m[i];
-    return r;
-}
-
-__device__ __forceinline__ uint32_t pack2(float a, float b) {          // one v_cvt_pk_bf16_f32
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
-    bf16x2v v;
-    v[0] = (__bf16)a; v[1] = (__bf16)b;
-    return __builtin_bit_cast(uint32_t, v);
-}
 template <int G, bool DROP>
 __device__ __forceinline__ void fwd_tile(const f32x16& st, float c2, float nm, float& l_run, f32x16& acc, const Masks16& mk, const char* Vs,
                                          int kt, int lane) {
@@ -641,8 +605,25 @@ static uint32_t keep_thresh(float p) {
     return (uint32_t)std::min(std::max(t, 1), one - 1);
 }
 extern "C" float mmfm_attn_keep_prob(float p) { return p <= 0.f ? 1.f : (float)keep_thresh(p) / (float)(1 << KEEP_BITS); }
+// bit tiles, then (dh = 64 kernels, attention_long.hip) one float per (b, head, query) for the backward's delta
 extern "C" int64_t mmfm_attn_keepbits_bytes(int B, int heads, int Lq, int Lk) {
-    return (int64_t)B * heads * ((Lq + 31) / 32) * ((Lk + 31) / 32) * 128;
+    const int64_t tiles = (int64_t)B * heads * ((Lq + 31) / 32) * ((Lk + 31) / 32) * 128;
+    return tiles + (((int64_t)B * heads * Lq * 4 + 127) & ~(int64_t)127);
+}
+
+// the generator launch of a forward with attention dropout on the keep-bit path
+int mmfm_attn_keepbits_launch(const mmfm_attn_desc& d, hipStream_t st) {
+    KeepArgs a;
+    a.bits = reinterpret_cast<uint32_t*>(d.keepbits);
+    a.state = reinterpret_cast<const uint32_t*>(d.drop_p.state);
+    a.site = d.drop_p.site;
+    a.thresh = keep_thresh(d.drop_p.p);
+    a.nkt = (d.Lk + 31) / 32;
+    a.Lk = d.Lk;
+    a.nwords = (uint32_t)((int64_t)d.B * d.heads * ((d.Lq + 31) / 32) * a.nkt * 32);
+    hipLaunchKernelGGL(attn_keepbits_kernel, dim3((a.nwords + 255) / 256), dim3(256), 0, st, a);
+    MMFM_LAUNCH_CHECK("mmfm_attn_fwd(keep bits)");
+    return 0;
 }
 
 // Shapes the fast kernels take.  Returns -1000 when the general kernels must run.
@@ -670,18 +651,7 @@ int mmfm_attn_fast_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st
     const int grid = d.B * d.heads;
     const float keep_scale = drop ? 1.f / mmfm_attn_keep_prob(d.drop_p.p) : 1.f;
     if (!backward) {
-        if (drop) {
-            KeepArgs a;
-            a.bits = reinterpret_cast<uint32_t*>(d.keepbits);
-            a.state = reinterpret_cast<const uint32_t*>(d.drop_p.state);
-            a.site = d.drop_p.site;
-            a.thresh = keep_thresh(d.drop_p.p);
-            a.nwords = (uint32_t)(mmfm_attn_keepbits_bytes(d.B, d.heads, d.Lq, d.Lk) / 4);
-            a.nkt = nkt;
-            a.Lk = d.Lk;
-            hipLaunchKernelGGL(attn_keepbits_kernel, dim3((a.nwords + 255) / 256), dim3(256), 0, st, a);
-            MMFM_LAUNCH_CHECK("mmfm_attn_fwd(keep bits)");
-        }
+        if (drop) { if (int rc = mmfm_attn_keepbits_launch(d, st)) return rc; }
         const int nw = nqt <= 4 ? 4 : (nqt == 7 ? 7 : (nqt <= 6 ? 6 : 8));
         const size_t lds = fwd_fast_lds(d.Lk, nw);
 #define FWDF3(NWV, DRP, NKT)                                                                                        \

@@ -115,4 +115,43 @@ __device__ __forceinline__ Drop16 drop16_init(mmfm_dropout d) {
     return r;
 }
 
+// ---- element-wise helpers of the keep-bit kernels (attention_fast.hip, attention_long.hip)
+// NO vector instruction of these kernels lives in inline asm.  Round 4 tried (v_add / v_max3 / v_cndmask / v_bfe in asm, to keep the
+// compiler from packing fp32 pairs or rewriting a bit test): every launch returned garbage.  gfx950 leaves several read-after-write
+// waits to software (an MFMA's result, a transcendental's, a permlane's) and the compiler inserts them only around instructions it
+// can see.  What shapes the code instead: -fno-slp-vectorize for this file (Makefile: v_pk_*_f32 is 8 issue cycles for two results,
+// no gain beside MFMAs), __builtin_amdgcn_inverse_ballot_w64 for "select by a scalar lane mask" (one v_cndmask_b32 with an SGPR pair),
+// and EMPTY asm statements as optimisation barriers only.
+__device__ __forceinline__ float v_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ float v_add(float a, float b) { return a + b; }
+__device__ __forceinline__ float v_mul(float a, float b) { return a * b; }
+// p where the lane's bit of `mask` is set, else 0
+__device__ __forceinline__ float v_keep(float p, uint64_t mask) { return __builtin_amdgcn_inverse_ballot_w64(mask) ? p : 0.f; }
+__device__ __forceinline__ float xhalf_max(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return v_max(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float v) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+
+// the 16 lane masks of one (query tile, key tile): register r's mask is the 64-bit pair (words 2 r, 2 r + 1) of the keep-bit tile
+struct Masks16 { uint64_t m[16]; };
+typedef const Masks16 __attribute__((address_space(4))) * masks_ptr;      // constant address space: scalar loads
+__device__ __forceinline__ Masks16 ld_masks(masks_ptr p) {
+    Masks16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r.m[i] = p->m[i];
+    return r;
+}
+
+__device__ __forceinline__ uint32_t pack2(float a, float b) {          // one v_cvt_pk_bf16_f32
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2v;
+    bf16x2v v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
 }  // namespace attn

@@ -174,7 +174,11 @@ class MultiModal(nn.Module):
         mod_loss, mod_n, preds, targets = {}, {}, {}, {}
         for i, mod in enumerate(mods):
             mod_loss[mod], mod_n[mod] = out["mod_loss"][i], out["mod_n"][i]
-            preds[mod] = out["preds"][i] if out["preds"][i].dtype == torch.float32 else out["preds"][i].float()
+            # bf16 engine: the fp32 copy of the predictions (68 M elements for 'ap' at B = 1024: a 410 MB cast kernel per step) is made
+            # where somebody reads them - evaluation; in training mode (the trainer's train_epoch only reads the loss) mod_preds
+            # carries the engine's bf16 predictions as they are
+            p_ = out["preds"][i]
+            preds[mod] = p_ if (p_.dtype == torch.float32 or self.training) else p_.float()
             targets[mod] = mod_dict[mod]['targets']
             mod_dict[mod]['gt'], mod_dict[mod]['preds'] = targets[mod], preds[mod]
         return MultiModalOutput(loss=out["loss"], mod_loss=mod_loss, mod_n_examples=mod_n, mod_preds=preds, mod_targets=targets)

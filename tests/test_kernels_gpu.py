@@ -733,7 +733,7 @@ def _unpack_keepbits(kb, B, heads, Lq, Lk):
     """keep[b, h, q, k] out of the documented bit-tile layout (csrc/attention_fast.hip header): words [bh][qt][kt][32], word 2 r + kh
     of a tile = key 32 kt + (r & 3) + 8 (r >> 2) + 4 kh, bit j = query 32 qt + j."""
     nqt, nkt = (Lq + 31) // 32, (Lk + 31) // 32
-    w = kb.view(torch.int32).view(B * heads, nqt, nkt, 32).cpu().numpy().astype(np.uint32)
+    w = kb[:B * heads * nqt * nkt * 128].view(torch.int32).view(B * heads, nqt, nkt, 32).cpu().numpy().astype(np.uint32)      # (behind the tiles: scratch)
     bits = ((w[..., None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool)          # [bh, qt, kt, word, qbit]
     widx = np.arange(32)
     key_of_word = ((widx >> 1) & 3) + 8 * (widx >> 3) + 4 * (widx & 1)
@@ -798,6 +798,60 @@ def test_attention_fast_dropout_matches_reference(ops, B, heads, Lq, Lk, flags, 
     close_bf16(dq, qr.grad, "fast attn dq", tol=3e-2)
     close_bf16(dkv[:, :H], kvr.grad[:, :H], "fast attn dk", tol=3e-2)
     close_bf16(dkv[:, H:], kvr.grad[:, H:], "fast attn dv", tol=3e-2)
+
+
+@pytest.mark.parametrize("B,heads,Lq,Lk,flags,pad,p", [(2, 2, 600, 600, 1, True, 0.4), (1, 2, 200, 200, 0, False, 0.4), (2, 1, 72, 136, 0, True, 0.0),
+                                                      (1, 2, 608, 600, 0, False, 0.25), (1, 1, 40, 24, 0, True, 0.4)])
+def test_attention_long_keepbit_kernels_match_reference(ops, B, heads, Lq, Lk, flags, pad, p):
+    """The dh = 64 keep-bit kernels (csrc/attention_long.hip: BASELINE configs[4], L = 600) against torch fp32 on the same bf16 inputs:
+    chunk-streamed forward with the first-tile reference exponent, prep + dK/dV + dQ backward.  The keep mask is read out of the bit
+    tiles the forward left (layout pinned by test_attention_fast_dropout_matches_reference against the dh = 32 forward's own output),
+    then softmax -> mask / keep -> P.V and its autograd give the expected output, LSE and all three gradients.  Keys of the last
+    quarter carry 6x larger rows (scores far above the first key tile's maximum)."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    dh = 64
+    H = heads * dh
+    q = bf(rnd(B * Lq, H, seed=1))
+    kv = rnd(B * Lk, 2 * H, seed=2)
+    kv.view(B, Lk, 2 * H)[:, (3 * Lk) // 4:, :H] *= 6.0
+    kv = bf(kv)
+    d_o = bf(rnd(B * Lq, H, seed=3))
+    kp = torch.ones(B, Lk, dtype=torch.uint8)
+    if pad:
+        kp[0, Lk - 3:] = 0
+        kp[B - 1, 5:9] = 0
+    kp = kp.cuda()
+    state = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.rng_seed(state, 99)
+    keep_p = ops.attn_keep_prob(p)
+    o, lse = torch.empty(B * Lq, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, Lq, device="cuda")
+    dq, dkv = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
+    kb = torch.zeros(ops.attn_keepbits_bytes(B, heads, Lq, Lk), dtype=torch.uint8, device="cuda")
+    desc = ops.attn_desc(Lb.BF16, B, heads, Lq, Lk, dh, q.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * 2, H, 2 * H, 2 * H, o.data_ptr(), H, lse,
+                         kp, None, flags, dh ** -0.5, drop_p=ops.dropout(state, 5, p), drop_o=ops.dropout(state, 6, 0.0), d_o=d_o.data_ptr(), lddo=H,
+                         dq=dq.data_ptr(), dk=dkv.data_ptr(), dv=dkv.data_ptr() + H * 2, lddq=H, lddk=2 * H, lddv=2 * H, keepbits=kb)
+    ops.attn_fwd(desc)
+    keep = _unpack_keepbits(kb, B, heads, Lq, Lk).cuda() if p > 0 else torch.ones(B, heads, Lq, Lk, dtype=torch.bool, device="cuda")
+    if p > 0:
+        rate = keep.float().mean().item()
+        assert abs(rate - keep_p) < 5 * math.sqrt(p * (1 - p) / keep.numel()) + 1e-4, f"keep rate {rate}"
+    ops.attn_bwd(desc)
+    m = kp.bool()[:, None, :].expand(B, Lq, Lk)
+    if flags & 1:
+        m = m | torch.eye(Lq, Lk, dtype=torch.bool, device="cuda")[None]
+    qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    Q = qr.view(B, Lq, heads, dh).transpose(1, 2)
+    K_, V_ = [t.view(B, Lk, heads, dh).transpose(1, 2) for t in kvr.split(H, dim=1)]
+    s = (Q @ K_.transpose(-1, -2)) * dh ** -0.5
+    s = s.masked_fill(~m[:, None], float("-inf"))
+    P = torch.softmax(s, -1)
+    oref = ((P * keep.float() / keep_p) @ V_).transpose(1, 2).reshape(B * Lq, H)
+    close_bf16(o, oref, "long attn fwd", tol=2e-2)
+    close(lse, torch.logsumexp(s, -1), rtol=1e-3, atol=2e-3, msg="long attn lse")
+    oref.backward(d_o.float())
+    close_bf16(dq, qr.grad, "long attn dq", tol=3e-2)
+    close_bf16(dkv[:, :H], kvr.grad[:, :H], "long attn dk", tol=3e-2)
+    close_bf16(dkv[:, H:], kvr.grad[:, H:], "long attn dv", tol=3e-2)
 
 
 def test_attention_fast_exact_pass_on_large_scores(ops):
