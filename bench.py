@@ -434,8 +434,10 @@ def main():
                 if fn.__name__ in ("mmfm_attn_fwd", "mmfm_attn_bwd"):
                     d = keep[0]
                     # measured instruction mix of the dh = 32 keep-bit kernels (csrc/attention_fast.hip): 6 issue slots per score element in
-                    # the forward (fma, exp x2, add, select, half a pack + the MFMAs' issue share), 9 in the backward; 64 elements per slot
-                    att_slots += (6.0 if fn.__name__.endswith("fwd") else 9.0) * d.B * d.heads * d.Lq * d.Lk / 64.0
+                    # the forward (fma, exp x2, add, select, half a pack + the MFMAs' issue share) + 3.6 for its decision in the generator
+                    # (114 instructions per 32-decision word), 9 in the backward; 64 elements per slot
+                    per = (6.0 + (3.6 if (d.keepbits and d.drop_p.p > 0) else 0.0)) if fn.__name__.endswith("fwd") else 9.0
+                    att_slots += per * d.B * d.heads * d.Lq * d.Lk / 64.0
             fams = [family("dense linears (x.W^T, dY.W, row-owner LN / MLP kernels)", FAM, sub_names=[k for k in subs if k != "dY^T.X"]),
                     family("weight gradients (dY^T.X, streaming split-K)", ("mmfm_gemm",), sub_names=["dY^T.X"]),
                     family("attention (dh 32 keep-bit kernels)", ("mmfm_attn_fwd", "mmfm_attn_bwd"), valu_slots=att_slots)]

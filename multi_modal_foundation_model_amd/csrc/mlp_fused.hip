@@ -112,11 +112,12 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
             }
         }
         const float rs = ld4f(RS, row * 4u);
-        if (dr.on()) {                                      // dropout'(dy): counter row*256 + k, k = 16s + 8h + j
+        if (dr.on()) {                                      // dropout'(dy): the row's keys, then features k = 16s + 8h + j (rowchain.h RowDrop)
+            const RowDrop rd = rowdrop_init(dr, row);
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 float f[8]; unpack8f(t1[s], f);
-                drop8(dr, f, row, 16 * s + 8 * h);
+                drop8(rd, f, 16 * s + 8 * h);
                 t1[s] = pack8o(f);
             }
         }
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
 #undef F8_READ
             STAMP(5);
         }
+        const RowDrop rd = rowdrop_init(dr, row);                               // (unused values when dropout is off)
         Lines xl2[2];                                                           // both residual line pairs requested together
 #pragma unroll
         for (int q = 0; q < 2; ++q) xl2[q] = fetch_lines(X, wrow0, ldxb, 128u * (2 * role + q), lane);
@@ -363,9 +365,7 @@ __global__ __launch_bounds__(NT8) void mlp_fwd8_kernel(const mmfm_mlp_desc d) {
             for (int j = 0; j < 2; ++j) {
                 const int t2 = 2 * lp + j;
                 add_vec(Yh[2 * q + j], lb_dn, t2, h);
-                if (dr.on()) {
-                    drop16(dr, Yh[2 * q + j], row, t2, h);
-                }
+                if (dr.on()) drop16(rd, Yh[2 * q + j], t2, h);
                 const f32x16 r = unstage_tile(stg, j, m, h);
 #pragma unroll
                 for (int i = 0; i < 16; ++i) Yh[2 * q + j][i] += r[i];

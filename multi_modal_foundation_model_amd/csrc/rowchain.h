@@ -490,23 +490,48 @@ __device__ __forceinline__ float ln_rows(opnd (&x)[16], float eps) {
     return rs;
 }
 
-// ---- dropout on an accumulator tile of output tile t2 (element counter row*256 + feature; registers i, i+1 with i even are
-// neighbouring features: one hash per pair)
-__device__ __forceinline__ void drop16(const Drop& dr, f32x16& v, uint32_t row, int t2, int h) {
+// ---- dropout of the fused MLP kernels (forward epilogue, backward prologue): a lane owns ONE token row, so the hash is two-level like the
+// attention kernels' (attn_common.h Drop16): a full-strength 2 x 32-bit key per ROW, made once per row pass, and a 7-instruction
+// xorshift / 24-bit-multiply mix of (feature pair ^ key A, key B) per pair of neighbouring features (even feature: low 16 bits, odd: high 16
+// bits, each against the top 16 bits of the threshold).  Round 3 ran the flat counter hash (row * 256 + feature: ~15 instructions per
+// pair, it has to digest a 26-bit counter) 64 times per lane in every backward pass - 14 % of that kernel.  Forward and backward
+// evaluate the same function; the un-fused kernels (GEMM epilogue + mmfm_dropout_apply, used below 12 k rows) keep the flat counter hash,
+// so the two plans draw different (equally distributed) masks.
+struct RowDrop {
+    uint32_t ka, kb, t16;
+    float scale;
+    __device__ __forceinline__ uint32_t pair(uint32_t fp) const {          // fp = feature >> 1 (< 128)
+        uint32_t h = __umul24(fp ^ ka, 0x7FEB35u) + kb;
+        h ^= h >> 13;
+        h = __umul24(h, 0x46CA6Bu);
+        h ^= h >> 16;
+        return h;
+    }
+};
+__device__ __forceinline__ RowDrop rowdrop_init(const Drop& dr, uint32_t row) {
+    RowDrop r;
+    r.ka = mix32(row ^ dr.k0);
+    r.kb = mix32((row + 0x9E3779B9u) ^ dr.k1);
+    r.t16 = dr.t16;
+    r.scale = dr.scale;
+    return r;
+}
+// ... on an accumulator tile of output tile t2 (registers i, i+1 with i even are neighbouring features: one hash per pair)
+__device__ __forceinline__ void drop16(const RowDrop& rd, f32x16& v, int t2, int h) {
 #pragma unroll
     for (int i = 0; i < 16; i += 2) {
-        const uint32_t hh = dr.hash((row * 256u + (uint32_t)feat(t2, i, h)) >> 1);      // tensors here are < 2^31 bytes
-        v[i] = dr.lo(hh) ? v[i] * dr.scale : 0.f;
-        v[i + 1] = dr.hi(hh) ? v[i + 1] * dr.scale : 0.f;
+        const uint32_t hh = rd.pair((uint32_t)feat(t2, i, h) >> 1);
+        v[i] = (hh & 0xffffu) >= rd.t16 ? v[i] * rd.scale : 0.f;
+        v[i + 1] = (hh >> 16) >= rd.t16 ? v[i + 1] * rd.scale : 0.f;
     }
 }
-// ... and on 8 consecutive features k0 .. k0+7 (k0 a multiple of 8) of `row`
-__device__ __forceinline__ void drop8(const Drop& dr, float (&f)[8], uint32_t row, int k0) {
+// ... and on 8 consecutive features k0 .. k0+7 (k0 a multiple of 8)
+__device__ __forceinline__ void drop8(const RowDrop& rd, float (&f)[8], int k0) {
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-        const uint32_t hh = dr.hash((row * 256u + (uint32_t)(k0 + j)) >> 1);
-        f[j] = dr.lo(hh) ? f[j] * dr.scale : 0.f;
-        f[j + 1] = dr.hi(hh) ? f[j + 1] * dr.scale : 0.f;
+        const uint32_t hh = rd.pair((uint32_t)(k0 + j) >> 1);
+        f[j] = (hh & 0xffffu) >= rd.t16 ? f[j] * rd.scale : 0.f;
+        f[j + 1] = (hh >> 16) >= rd.t16 ? f[j + 1] * rd.scale : 0.f;
     }
 }
 

@@ -9,7 +9,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT -o write --output-format csv -
 python3 - <<PY
 import csv, glob, json, collections
 FAM = [("rowgemm", "mmfm_rowgemm"), ("mlp_fwd", "mmfm_mlp_fwd"), ("mlp_bwd", "mmfm_mlp_bwd"), ("ln_linear_grad", "mmfm_ln_linear_grad"),
-       ("prep_weights", "mmfm_prep_weights"), ("gemm_bf16_kernel", "mmfm_gemm"), ("gemm_dw_kernel", "mmfm_gemm"), ("gemm_big_kernel", "mmfm_gemm"), ("gemm_f32_kernel", "mmfm_gemm"), ("attn_bwd", "mmfm_attn_bwd"), ("attn_fwd", "mmfm_attn_fwd"),
+       ("prep_weights", "mmfm_prep_weights"), ("gemm_bf16_kernel", "mmfm_gemm"), ("gemm_dw_kernel", "mmfm_gemm"), ("gemm_big_kernel", "mmfm_gemm"), ("gemm_f32_kernel", "mmfm_gemm"), ("attn_bwd", "mmfm_attn_bwd"), ("attn_fwd", "mmfm_attn_fwd"), ("attn_keepbits", "mmfm_attn_keepbits"),
        ("ln_bwd_kernel", "mmfm_layernorm_bwd"), ("ln_fwd_kernel", "mmfm_layernorm_fwd"), ("reduce_slabs", "mmfm_reduce_slabs"),
        ("adamw_kernel", "mmfm_adamw_step"), ("loss_", "mmfm_masked_loss"), ("stitch_", "mmfm_stitch"), ("onehot_kernel", "mmfm_stitch"),
        ("dropout_apply", "mmfm_dropout_apply")]

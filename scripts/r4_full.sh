@@ -3,4 +3,6 @@
 set -o pipefail
 O=gpurun_out/r4d; mkdir -p $O
 timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
-timeout -k 10 500 python bench.py > $O/bench_bf16_B1024.json 2> $O/bench.err; echo "bench rc=$?"; tail -c 1500 $O/bench_bf16_B1024.json; echo
+timeout -k 10 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra-legs > $O/bench_short.json 2> $O/bench.err; echo "bench rc=$?"
+python -c "
+import json; d=json.loads(open('$O/bench_short.json').read().strip().splitlines()[-1]); print(d['ms_per_step'], d['kernel_breakdown_ms'])"

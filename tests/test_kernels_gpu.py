@@ -629,15 +629,16 @@ def test_attention_bf16_dropout_consistency(ops, L, dh):
     close(dv.sum(1), o.float().view(B, L, heads, dh)[..., 0].sum(1), rtol=2e-2, atol=0.5, msg="bf16 fwd/bwd dropout mask agree")
 
 
-def test_gemm_bf16_dw_stream_padded_rows(ops):
+@pytest.mark.parametrize("R,kchunk", [(6400, 1600), (40960, 2048)])
+def test_gemm_bf16_dw_stream_padded_rows(ops, R, kchunk):
     """The tokeniser's weight gradient (1336 x 668, K = B*T tokens): X rows padded to a 16-B multiple (ld 672) so the streaming kernel takes the
-    shape although N % 8 = 4; the pad columns hold garbage that must not reach the 668 real ones."""
-    R, N, K, ld = 6400, 1336, 668, 672
+    shape although N % 8 = 4; the pad columns hold garbage that must not reach the 668 real ones.  R = 6,400 runs the 128-wide tile
+    instantiation, R = 40,960 (>= 32,768: the step's regime) the 256-wide one - gemm_dw_kernel<256, 32>, the only one in the B = 1024 step."""
+    N, K, ld = 1336, 668, 672
     dy = bf(rnd(R, N, seed=18))
     xp = torch.full((R, ld), float("nan"), device="cuda", dtype=torch.bfloat16)
     x = bf(rnd(R, K, seed=19))
     xp[:, :K] = x
-    kchunk = 1600
     splits = R // kchunk
     stride = (N * K + N + 7) // 8 * 8
     slabs = torch.full((splits, stride), float("nan"), device="cuda")
@@ -703,6 +704,33 @@ def _gemm_bf16_256_tile_kernel(ops, M, N, K, Kreal):
     ops.gemm(x, w, y0, M, N, K, lda=K, ldb=K, ldc=N, gradmul_pre=a_out, act=5, act_scale=0.7)
     close_bf16(y0, (x.double() @ w.double().T) * 0.7 * (1 - a_out.double().abs() / 0.7) ** 2, "256-tile softsign' from the output")
     close_bf16(y0, (x.double() @ w.double().T) * 0.7 / (1 + ud.abs()) ** 2, "256-tile softsign' from the output vs exact", tol=2.5e-2)
+
+
+def test_gemm_act5_softsign_grad_from_output_error_bound(ops):
+    """act 5 rebuilds softsign'(x) = 1 / (1 + |x|)^2 as (1 - |y| / s)^2 from the bf16-STORED activation y = s x / (1 + |x|).
+    Near |y| -> s this cancels: bf16 spacing there is s 2^-8, so r = 1 - |y| / s carries an ABSOLUTE error of up to 2^-9 ~ 2e-3 and the
+    factor r^2 an absolute error of <= 2 r 2^-9 + 2^-18 - small against the gradients of moderate pre-activations, the whole value once
+    |x| > ~250 (y rounds to s, the gradient reads exactly 0 where the true factor is 1.6e-5).  Pinned here over |x| in [0, 300]:
+    absolute error of the factor <= 1.5 (2^-8 r + 2^-17) (+ the bf16 rounding of the product) everywhere, i.e. a RELATIVE error of about
+    0.6 % x (1 + |x|): 5 % at |x| = 8, 20 % at |x| = 32 (checked up to there), the whole value beyond |x| ~ 170."""
+    M, N, K, s_ = 64, 512, 64, 0.7
+    xs = torch.cat([torch.linspace(0, 8, M * N // 2), torch.linspace(8, 300, M * N // 2)])[torch.randperm(M * N, generator=torch.Generator().manual_seed(3))]
+    xs = (xs * torch.where(torch.rand(M * N, generator=torch.Generator().manual_seed(4)) < 0.5, -1.0, 1.0)).view(M, N).cuda()
+    y_act = bf(s_ * xs / (1 + xs.abs()))
+    a = bf(torch.eye(M, K, device="cuda"))                    # dY = a @ w^T picks columns of w: dY[m, n] = w[n, m]
+    w = bf(rnd(N, K, seed=5) + 2.0 * torch.sign(rnd(N, K, seed=6)))          # |w| >= ~1: the factor is read off out / w
+    out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    ops.gemm(a, w, out, M, N, K, lda=K, ldb=K, ldc=N, gradmul_pre=y_act, act=5, act_scale=s_)
+    base = a.double() @ w.double().T
+    got = out.double() / base                                  # the applied factor, per element
+    r = 1 / (1 + xs.double().abs())
+    true = s_ * r * r
+    err = (got - true).abs()
+    bound = 1.5 * (s_ * (2.0 ** -8 * r + 2.0 ** -17) + 2.0 ** -8 * true + 2.0 ** -9 * got.abs())      # + bf16 rounding of the stored product; x1.5 slack
+    assert bool((err <= bound).all()), f"max excess {(err - bound).max().item():.3e}"
+    rel_bound = 1.5 * 2.0 ** -8 * (1 + xs.double().abs()) + 2.0 ** -7           # ~0.6 % x (1 + |x|): 5 % at |x| = 8, the whole value beyond ~170
+    small = xs.abs() <= 32
+    assert bool((err[small] / true[small] <= rel_bound[small]).all())
 
 
 def _extract_attn_keep_mask(ops, state, site, p, B, heads, Lq, Lk):
