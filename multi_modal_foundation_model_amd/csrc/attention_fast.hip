@@ -111,7 +111,7 @@ constexpr float F_OVERFLOW = 1.2676506e30f;                    // 2^100: a row s
 
 // NKT = key tiles of the head when known at compile time (7: the L = 200 / 224 step shapes), 0 = read from the descriptor.
 template <int NW, bool DROP, int NKT>
-__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_fast_kernel(const mmfm_attn_desc d, const float keep_scale, const int warm_dist) {
+__global__ __launch_bounds__(NW * 64, 4) void attn_fwd_fast_kernel(const mmfm_attn_desc d, const float keep_scale) {
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, kh = lane >> 5, l31 = lane & 31;
@@ -171,21 +171,7 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_fast_kernel(const mmfm_at
 #pragma unroll
     for (int w = 0; w < NW; ++w) anypad |= wflag[w];
     anypad = __builtin_amdgcn_readfirstlane(anypad);     // the same word in every lane: tell the compiler, or `dfix` is a divergent branch
-    // L2 warm-up for a LATER workgroup: this one's operands are in LDS, its memory pipe is idle until the output stores.  One dword per
-    // 128-byte line of the Q / K / V rows of the head `warm_dist` workgroups ahead in dispatch order (= the workgroup that will take
-    // this one's place on the chip; warm_dist % 8 == 0: same XCD, same L2) - that workgroup's prologue, a single round trip it waits out
-    // with nothing to do, then hits the L2 instead of HBM.  The values are consumed by an empty asm at the very end (nothing waits
-    // for them before).
-    uint32_t wq_ = 0u, wk_ = 0u, wv_ = 0u;
-    if (warm_dist > 0 && (int)blockIdx.x + warm_dist < (int)gridDim.x) {
-        const int nh = attn_xcd_remap((int)blockIdx.x + warm_dist, (int)gridDim.x, d.flags), nb_ = nh / d.heads, nhh = nh % d.heads;
-        if (t < Lk) {
-            wk_ = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(d.k) + ((size_t)nb_ * Lk + t) * d.ldk + nhh * 32);
-            wv_ = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(d.v) + ((size_t)nb_ * Lk + t) * d.ldv + nhh * 32);
-        }
-        if (t < Lq) wq_ = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(d.q) + ((size_t)nb_ * Lq + t) * d.ldq + nhh * 32);
-    }
-    if (qt >= nqt) { asm volatile("" :: "v"(wq_), "v"(wk_), "v"(wv_)); return; }
+    if (qt >= nqt) return;
 
     bf16x8v qf[2];
     qf[0] = __builtin_bit_cast(bf16x8v, qv[0]);
@@ -309,7 +295,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attn_fwd_fast_kernel(const mmfm_at
         if (q0 + row < Lq)
             *reinterpret_cast<uint4*>(og + (size_t)(q0 + row) * ldo + 8 * c) = *reinterpret_cast<const uint4*>(tl + row * F_ORS + c * 16);
     }
-    asm volatile("" :: "v"(wq_), "v"(wk_), "v"(wv_));     // the warm-up loads' only consumer
 }
 
 size_t fwd_fast_lds(int Lk, int nw) {
@@ -396,7 +381,7 @@ __device__ __forceinline__ void bwd_tile(const f32x16& s, const f32x16& dpv, flo
 // NQT = query tiles of the head when known at compile time (7: the L = 200 / 224 step shapes - the query-tile loop is then straight-line
 // code and every LDS address in it a lane constant plus an immediate), 0 = read from the descriptor.
 template <bool DROP, int NQT>
-__global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_attn_desc d, const float keep_scale, const int warm_dist) {
+__global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_attn_desc d, const float keep_scale) {
     constexpr int NW = B_NW, CW = B_CW, TS = B_TS, TILE = B_TILE, RS = B_RS, NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int t = threadIdx.x, lane = t & 63, kh = lane >> 5, l31 = lane & 31;
@@ -494,20 +479,6 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
     for (int w = 0; w < NW; ++w) anypad |= (int)flags[w];
     anypad = __builtin_amdgcn_readfirstlane(anypad);
     const float c2 = d.scale * LOG2E;
-    // L2 warm-up for the workgroup `warm_dist` ahead in dispatch order (see the forward): Q, K, V, d_o, o rows of its head
-    uint32_t w0_ = 0u, w1_ = 0u, w2_ = 0u, w3_ = 0u, w4_ = 0u;
-    if (warm_dist > 0 && (int)blockIdx.x + warm_dist < (int)gridDim.x) {
-        const int nh = attn_xcd_remap((int)blockIdx.x + warm_dist, (int)gridDim.x, d.flags), nb_ = nh / d.heads, nhh = nh % d.heads;
-        if (t < Lk) {
-            w0_ = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(d.k) + ((size_t)nb_ * Lk + t) * d.ldk + nhh * 32);
-            w1_ = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(d.v) + ((size_t)nb_ * Lk + t) * d.ldv + nhh * 32);
-        }
-        if (t < Lq) {
-            w2_ = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(d.q) + ((size_t)nb_ * Lq + t) * d.ldq + nhh * 32);
-            w3_ = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(d.d_o) + ((size_t)nb_ * Lq + t) * d.lddo + nhh * 32);
-            w4_ = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint16_t*>(d.o) + ((size_t)nb_ * Lq + t) * d.ldo + nhh * 32);
-        }
-    }
 
     if (wave < CW) {
         // ---------------- compute waves: one key tile each, all query tiles
@@ -618,7 +589,6 @@ __global__ __launch_bounds__(B_NW * 64, 4) void attn_bwd_fast_kernel(const mmfm_
             for (int qt = 0; qt < nqt; ++qt) step(qt);
         }
     }
-    asm volatile("" :: "v"(w0_), "v"(w1_), "v"(w2_), "v"(w3_), "v"(w4_));     // the warm-up loads' only consumer
 }
 
 size_t bwd_fast_lds(int Lq, int Lk) {
@@ -680,9 +650,6 @@ int mmfm_attn_fast_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st
     }
     const int grid = d.B * d.heads;
     const float keep_scale = drop ? 1.f / mmfm_attn_keep_prob(d.drop_p.p) : 1.f;
-    // L2 warm-up distance in workgroups (2 per CU x 256 CUs in flight; a multiple of 8 keeps the XCD); 0 = off
-    const int warm = (backward ? [] { const char* e = getenv("MMFM_ATTN_WARM_BWD"); return e ? atoi(e) : 0; }()
-                               : [] { const char* e = getenv("MMFM_ATTN_WARM"); return e ? atoi(e) : 512; }()) & ~7;
     if (!backward) {
         if (drop) { if (int rc = mmfm_attn_keepbits_launch(d, st)) return rc; }
         const int nw = nqt <= 4 ? 4 : (nqt == 7 ? 7 : (nqt <= 6 ? 6 : 8));
@@ -691,7 +658,7 @@ int mmfm_attn_fast_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st
         {                                                                                                           \
             auto kern = attn_fwd_fast_kernel<NWV, DRP, NKT>;                                                        \
             if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(kern), lds, "mmfm_attn_fwd(bf16, dh 32)")) return rc; \
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, d, keep_scale, warm);                     \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(NWV * 64), lds, st, d, keep_scale);                           \
         }
 #define FWDF(NWV)                                                                                                   \
         {                                                                                                           \
@@ -709,7 +676,7 @@ int mmfm_attn_fast_launch(const mmfm_attn_desc& d, bool backward, hipStream_t st
     {                                                                                                               \
         auto kern = attn_bwd_fast_kernel<DRP, NQ>;                                                                  \
         if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(kern), lds, "mmfm_attn_bwd(bf16, dh 32)")) return rc; \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(B_NW * 64), lds, st, d, keep_scale, warm);                        \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(B_NW * 64), lds, st, d, keep_scale);                              \
     }
     if (drop) { if (nqt == 7) BWDF3(true, 7) else BWDF3(true, 0) }
     else { if (nqt == 7) BWDF3(false, 7) else BWDF3(false, 0) }
