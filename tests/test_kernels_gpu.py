@@ -882,6 +882,45 @@ def test_attention_long_keepbit_kernels_match_reference(ops, B, heads, Lq, Lk, f
     close_bf16(dkv[:, H:], kvr.grad[:, H:], "long attn dv", tol=3e-2)
 
 
+def test_attention_long_exact_pass_on_large_scores(ops):
+    """dh = 64 forward (csrc/attention_long.hip): rows whose sum overflows against the first key tile's maximum send the WORKGROUP (a vote
+    through LDS: the chunk barriers need every wave) through the exact pass.  Keys 32.. carry 40x larger rows, one head's first tile is
+    fully padded; Lq spans two workgroups (8 query tiles each) so that a redo and a no-redo workgroup run side by side."""
+    from multi_modal_foundation_model_amd import _lib as Lb
+    B, heads, L, dh = 2, 2, 328, 64
+    H = heads * dh
+    q = bf(rnd(B * L, H, seed=21) * 2.0)
+    kv = rnd(B * L, 2 * H, seed=22)
+    kv.view(B, L, 2 * H)[:, 32:, :H] *= 40.0
+    q.view(B, L, H)[:, 256:] *= 0.0                                      # the second workgroup's rows: flat scores, no overflow, no redo
+    kv = bf(kv)
+    d_o = bf(rnd(B * L, H, seed=23))
+    kp = torch.ones(B, L, dtype=torch.uint8)
+    kp[1, :32] = 0
+    kp = kp.cuda()
+    o, lse = torch.empty(B * L, H, device="cuda", dtype=torch.bfloat16), torch.empty(B, heads, L, device="cuda")
+    dq, dkv = torch.full_like(q, float("nan")), torch.full_like(kv, float("nan"))
+    kb = torch.zeros(ops.attn_keepbits_bytes(B, heads, L, L), dtype=torch.uint8, device="cuda")
+    desc = ops.attn_desc(Lb.BF16, B, heads, L, L, dh, q.data_ptr(), kv.data_ptr(), kv.data_ptr() + H * 2, H, 2 * H, 2 * H, o.data_ptr(), H, lse,
+                         kp, None, 0, dh ** -0.5, d_o=d_o.data_ptr(), lddo=H, dq=dq.data_ptr(), dk=dkv.data_ptr(), dv=dkv.data_ptr() + H * 2,
+                         lddq=H, lddk=2 * H, lddv=2 * H, keepbits=kb)
+    ops.attn_fwd(desc)
+    ops.attn_bwd(desc)
+    qr, kvr = q.float().requires_grad_(True), kv.float().requires_grad_(True)
+    Q = qr.view(B, L, heads, dh).transpose(1, 2)
+    K_, V_ = [t.view(B, L, heads, dh).transpose(1, 2) for t in kvr.split(H, dim=1)]
+    s = (Q @ K_.transpose(-1, -2)) * dh ** -0.5
+    assert s.max().item() > 150
+    s = s.masked_fill(~kp.bool()[:, None, None, :], float("-inf"))
+    oref = (torch.softmax(s, -1) @ V_).transpose(1, 2).reshape(B * L, H)
+    close_bf16(o, oref, "long exact-pass fwd", tol=2e-2)
+    close(lse, torch.logsumexp(s, -1), rtol=1e-3, atol=2e-2, msg="long exact-pass lse")
+    oref.backward(d_o.float())
+    close_bf16(dq, qr.grad, "long exact-pass dq", tol=3e-2)
+    close_bf16(dkv[:, :H], kvr.grad[:, :H], "long exact-pass dk", tol=3e-2)
+    close_bf16(dkv[:, H:], kvr.grad[:, H:], "long exact-pass dv", tol=3e-2)
+
+
 def test_attention_fast_exact_pass_on_large_scores(ops):
     """The fast forward keeps the first key tile's row maximum as the reference exponent for the whole row (no running maximum); a
     row whose later scores overflow against it must come out of the exact pass instead.  Keys 32.. carry 40x larger rows than the
