@@ -348,7 +348,8 @@ typedef struct {
     const void* w_down_t;             /* bf16 [512][256] */
     const void* w_up_t;               /* bf16 [256][512] (prepared, unit-permuted: WpTP) */
     void* t1; void* g; void* du;
-    void* dx; int lddx;
+    void* dx; int lddx;               /* dx == NULL: front half only - t1, g, du are written and the call returns; rstd / w_up_t are not read.
+                                         The caller finishes with mmfm_rowgemm(x = du, w = WpT of up_proj, K = 512, residual = dy, ln_bwd) */
     int rotate;                       /* 1: workgroups start at different intermediate tiles (spreads the concurrent L2 reads) */
 } mmfm_mlp_desc;
 int mmfm_mlp_fwd(const mmfm_mlp_desc* d, mmfm_stream stream);

@@ -243,6 +243,111 @@ __global__ __launch_bounds__(NT) void mlp_bwd_kernel(const mmfm_mlp_desc d) {
     STAMP_FLUSH;
 }
 
+// ------------------------------------------------------------------------------------------------ backward, front half only
+// mmfm_mlp_bwd with dx == NULL: t1 = dropout'(dy), g = gelu(u), du = dg * gelu'(u) for every row and NOTHING else - no d(x_hat)
+// accumulators (128 registers of the kernel above), no x_hat stash, no LayerNorm-backward epilogue.  The caller finishes with
+// mmfm_rowgemm(ln_bwd): dx = dy + LN'(du . Wp_up) (the K = 512 dX + LayerNorm-backward kernel the key/value linear already uses).
+// What the split buys: this half fits 256 registers, so EIGHT waves share a workgroup's weight ring (two per SIMD - the fused kernel
+// runs one wave per SIMD at 448 registers and pays every LDS / MFMA latency once) and a pass streams 2 x 256 KB of weights for 256
+// rows instead of 3 x 256 KB for 128; what it costs: du is read back once (210 MB at R = 204,800).
+constexpr int NTD = 512, NWD = 8;
+__global__ __launch_bounds__(NTD, 2) void mlp_bwd_du_kernel(const mmfm_mlp_desc d) {
+    constexpr int RING_B = RINGA_SLOTS * CHUNK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];        // RING_B + 2 * NWD * STG_BYTES + 512 * 4
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
+    const int64_t npass = (d.R + 32 * NWD - 1) / (32 * NWD);
+    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
+    if (my_passes == 0) return;
+    const __amdgpu_buffer_rsrc_t rs_up = wbuf(d.w_up), rs_dnt = wbuf(d.w_down_t);
+    const int rot = d.rotate ? (int)(blockIdx.x & 7) * 2 : 0;            // even: tile pairs of g / du complete together
+    auto src = [=](int g) {                                               // up(ti) dg(ti), ti = 0..15
+        const int idx = g & 31, ti = idx >> 1, tt = (ti + rot) & 15;
+        AChunk c;
+        if ((idx & 1) == 0) { c.rs = rs_up; c.off = (uint32_t)(32 * tt) * 512u; c.ldb = 512u; c.kind = 0; }
+        else { c.rs = rs_dnt; c.off = (uint32_t)(32 * tt) * 512u; c.ldb = 512u; c.kind = 0; }
+        return c;
+    };
+    char* stg_g = smem + RING_B + wave * STG_BYTES;
+    char* stg_du = smem + RING_B + (NWD + wave) * STG_BYTES;
+    char* stg = stg_g;                                                   // prologue staging: the loop's g area is idle then
+    float* lb_up = reinterpret_cast<float*>(smem + RING_B + 2 * NWD * STG_BYTES);
+    stage_vec(lb_up, d.b_up, 512, t, NTD);
+    const Drop dr = drop_init(d.drop);
+    const GBuf XH = gbuf(d.xhat, d.R * 512), DY = gbuf(d.dy, d.R * d.lddy * 2), T1 = gbuf(d.t1, d.R * 512);
+    const GBuf G = gbuf(d.g, d.R * 1024), DU = gbuf(d.du, d.R * 1024);
+    const uint32_t lddyb = d.lddy * 2;
+    const ALane<NTD> ring_al = alane_init<NTD>(t, 512u, 1024u);
+    const AFrag fr = afrag_init(m, h);
+    RINGA_DECL(NTD);
+    RINGA_START((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem, my_passes * 32, src);
+    for (int pi = 0; pi < my_passes; ++pi) {
+        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NWD + wave) * 32);
+        const uint32_t row = wrow0 + m;
+        opnd x[16], t1[16];
+        {   // x_hat and dy rows requested in the same breath (one round trip for both row blocks)
+            Lines L[4], Ld[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) L[q] = fetch_lines(XH, wrow0, 512u, 128u * q, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Ld[q] = fetch_lines(DY, wrow0, lddyb, 128u * q, lane);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                stage_lines(stg, L[q], lane);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) x[4 * q + s4] = unstage_opnd(stg, s4, m, h);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                stage_lines(stg, Ld[q], lane);
+#pragma unroll
+                for (int s4 = 0; s4 < 4; ++s4) t1[4 * q + s4] = unstage_opnd(stg, s4, m, h);
+            }
+        }
+        if (dr.on()) {                                      // dropout'(dy) (rowchain.h RowDrop: the forward's decisions)
+            const RowDrop rd = rowdrop_init(dr, row);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                float f[8]; unpack8f(t1[s], f);
+                drop8(rd, f, 16 * s + 8 * h);
+                t1[s] = pack8o(f);
+            }
+        }
+        store_rows_lines<4, true>(stg, T1, wrow0, 512u, lane, m, h, t1);
+        // ODD tiles complete a pair of g / du tiles: their 16 line stores leave at the end of the iteration, and the next two ring steps
+        // may therefore leave eight more operations in flight (the EXTRA argument of RINGA_SYNC; same accounting as the fused kernel)
+#define MLP_DU_TILE(TI, ODD, EXTRA_AB)                                                           \
+        {                                                                                        \
+            const int ti = (TI), tt = (ti + rot) & 15;                                           \
+            uint32_t slot;                                                                       \
+            f32x16 U, DG;                                                                        \
+            {                                                                                    \
+                RINGA_SYNC(src, slot, EXTRA_AB);                                                 \
+                U = mma16a<4>(slot, fr, x, zero16(), [&](int g_) { if (g_ < 1024 / NTD) RINGA_PIECE(g_); }); \
+            }                                                                                    \
+            add_vec(U, lb_up, tt, h);                                                            \
+            {                                                                                    \
+                RINGA_SYNC(src, slot, EXTRA_AB);                                                 \
+                DG = mma16a<4>(slot, fr, t1, zero16(), [&](int g_) { if (g_ < 1024 / NTD) RINGA_PIECE(g_); }); \
+            }                                                                                    \
+            f32x16 Gt;                                                                           \
+            gelu_fwd_bwd16(U, Gt, DG);                                                           \
+            stage_tile(stg_g, ODD, m, h, Gt);                                                    \
+            stage_tile(stg_du, ODD, m, h, DG);                                                   \
+            if (ODD) {                          /* the pair (tt-1, tt) is complete -> whole 128-B lines */ \
+                flush_lines<true>(stg_g, G, wrow0, 1024u, 64u * (tt - 1), lane);                 \
+                flush_lines<true>(stg_du, DU, wrow0, 1024u, 64u * (tt - 1), lane);               \
+            }                                                                                    \
+        }
+        MLP_DU_TILE(0, 0, 0)
+        MLP_DU_TILE(1, 1, 0)
+        for (int tp = 1; tp < 8; ++tp) {
+            MLP_DU_TILE(2 * tp, 0, 8)
+            MLP_DU_TILE(2 * tp + 1, 1, 0)
+        }
+#undef MLP_DU_TILE
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ wave-pair versions
 // Forward: waves w and w+4 own the SAME 32 rows and split the work, so each fits 256 registers and every SIMD runs two waves
 // (VALU of one beside MFMAs of the other): both hold x_hat; wave A takes intermediate tiles 2u, wave B 2u+1 (up-projection + GELU),
@@ -449,8 +554,8 @@ int check(const mmfm_mlp_desc& d, bool bwd) {
     MMFM_REQUIRE(al16(d.x) && al16(d.w_up) && al16(d.w_down) && al16(d.y) && al16(d.xhat) && al16(d.dy) && al16(d.w_down_t) && al16(d.w_up_t) &&
                  al16(d.t1) && al16(d.g) && al16(d.du) && al16(d.dx) && al16(d.b_up) && al16(d.b_down), "mmfm_mlp: operands must be 16-byte aligned");
     if (!bwd) MMFM_REQUIRE(d.x && d.w_down && d.b_down && d.y && d.ldx % 8 == 0 && d.ldy % 8 == 0 && d.ldx >= 256 && d.ldy >= 256, "mmfm_mlp_fwd: bad arguments");
-    else MMFM_REQUIRE(d.xhat && d.rstd && d.dy && d.w_down_t && d.w_up_t && d.g && d.du && d.dx && d.lddy % 8 == 0 && d.lddx % 8 == 0 && d.lddy >= 256 &&
-                      d.lddx >= 256, "mmfm_mlp_bwd: bad arguments");
+    else MMFM_REQUIRE(d.xhat && d.dy && d.w_down_t && d.g && d.du && d.t1 && d.lddy % 8 == 0 && d.lddy >= 256 &&
+                      (d.dx == nullptr || (d.rstd && d.w_up_t && d.lddx % 8 == 0 && d.lddx >= 256)), "mmfm_mlp_bwd: bad arguments");
     return 0;
 }
 
@@ -473,6 +578,13 @@ extern "C" int mmfm_mlp_bwd(const mmfm_mlp_desc* dp, mmfm_stream stream) {
     const mmfm_mlp_desc d = *dp;
     if (int rc = check(d, true)) return rc;
     static const int per_cu = [] { const char* e = getenv("MMFM_MLP_WG_PER_CU"); const int v = e ? atoi(e) : 1; return v > 0 ? v : 1; }();
+    if (d.dx == nullptr) {            // front half only (t1, g, du): the caller finishes with mmfm_rowgemm(ln_bwd)
+        constexpr int LDS_D = RINGA_SLOTS * CHUNK + 2 * NWD * STG_BYTES + 512 * 4;
+        if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(mlp_bwd_du_kernel), LDS_D, "mmfm_mlp_bwd(front half)")) return rc;
+        hipLaunchKernelGGL(mlp_bwd_du_kernel, dim3(grid_for(d.R, per_cu, NWD)), dim3(NTD), LDS_D, (hipStream_t)stream, d);
+        MMFM_LAUNCH_CHECK("mmfm_mlp_bwd(front half)");
+        return 0;
+    }
     constexpr int LDS_B = RINGA_SLOTS * CHUNK + 2 * NW * STG_BYTES + 512 * 4 + NW * 4 * STG_BYTES;
     if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(mlp_bwd_kernel), LDS_B, "mmfm_mlp_bwd")) return rc;
     hipLaunchKernelGGL(mlp_bwd_kernel, dim3(grid_for(d.R, per_cu)), dim3(NT), LDS_B, (hipStream_t)stream, d);

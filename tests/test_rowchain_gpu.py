@@ -187,6 +187,38 @@ def test_mlp_backward(ops, R):
     check(dx[:R], xd.grad, 1.2e-2, "dx")
 
 
+@pytest.mark.parametrize("R,p", [(128, 0.0), (1000, 0.0), (2333, 0.4)])
+def test_mlp_backward_front_half_plus_rowgemm(ops, R, p):
+    """mmfm_mlp_bwd with dx == NULL stops after t1 / g / du (eight-wave kernel); mmfm_rowgemm(ln_bwd) on du finishes dx.  t1, g, du must
+    be the fused kernel's bit for bit (same operands, same MFMA order, same dropout decisions) and dx must match it to bf16 rounding."""
+    x, Wu, bu, Wd, bd, g, bt, up, dn = mlp_setup(ops, R, seed=60)
+    drop = None
+    if p > 0:
+        state = torch.zeros(2, dtype=torch.int32, device="cuda")
+        ops.rng_seed(state, 11)
+        drop = ops.dropout(state, 3, p)
+    y, xhat, rstd = torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, 256, device="cuda", dtype=BF), torch.empty(R, device="cuda")
+    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["WpP"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd, drop=drop))
+    dy = rnd(R, 256, seed=78).to(BF)
+    mk = lambda n: torch.full((R + 1, n), 5.0, device="cuda", dtype=BF)
+    t1, gg, du, dx = mk(256), mk(512), mk(512), mk(256)
+    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], drop=drop, xhat=xhat, rstd=rstd, dy=dy, w_down_t=dn["WpT"], w_up_t=up["WpTP"],
+                             t1=t1, g=gg, du=du, dx=dx))
+    t1h, ggh, duh, dxh = mk(256), mk(512), mk(512), mk(256)
+    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], drop=drop, xhat=xhat, dy=dy, w_down_t=dn["WpT"], t1=t1h, g=ggh, du=duh, dx=None))
+    ops.rowgemm(duh, up["WpT"], dxh, R, 256, 512, ldw=512, residual=dy, ldr=256, ln_bwd=True, bwd_xhat=xhat, bwd_rstd=rstd)
+    assert torch.equal(t1h, t1) and torch.equal(ggh, gg) and torch.equal(duh, du)
+    for b in (t1h, ggh, duh, dxh):
+        assert torch.all(b[R:] == 5.0)
+    check(dxh[:R], dx[:R].double(), 1.2e-2, "dx (front half + rowgemm) vs fused")
+    if p == 0:
+        xd = x.double().requires_grad_(True)
+        h = F.layer_norm(xd, (256,), g.double(), bt.double(), 1e-5)
+        out = xd + F.gelu(h @ Wu.double().T + bu.double()) @ Wd.double().T + bd.double()
+        out.backward(dy.double())
+        check(dxh[:R], xd.grad, 1.2e-2, "dx (front half + rowgemm) vs autograd")
+
+
 def test_ln_linear_grad_matches_autograd(ops):
     """dW, db of the linear and dgamma, dbeta of the LayerNorm in front of it from G = dY^T x_hat and db = colsum dY."""
     R, N, K = 700, 96, 256
