@@ -41,6 +41,7 @@ def parse():
                     help="batches start in pinned HOST memory and cross PCIe inside the timed region (the PCIe-inclusive rate quoted in "
                          "DESIGN.md; never the headline `value`, which is measured with inputs resident in HBM)")
     ap.add_argument("--no-kernel-profile", action="store_true")
+    ap.add_argument("--host-profile", default=None, help="write a cProfile summary of the timed loop's host side to this file (diagnostic)")
     ap.add_argument("--no-extra-legs", action="store_true", help="skip the short fp32 / exact-masker / multi-session / config-5 legs")
     ap.add_argument("--cpu-steps", type=int, default=12, help="CPU-baseline steps at B=16 (~1 s each on 16 threads: a 10-15 s bounded sample)")
     return ap.parse_args()
@@ -349,9 +350,22 @@ def main():
     barrier()
     if rank == 0:
         log(f"timing {a.steps} steps")
+    prof = None
+    if a.host_profile and rank == 0:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)
+    if prof is not None:
+        prof.disable()
+        import io, pstats
+        buf_ = io.StringIO()
+        pstats.Stats(prof, stream=buf_).sort_stats("cumulative").print_stats(70)
+        with open(a.host_profile, "w") as fh:
+            fh.write(buf_.getvalue())
+    dt_host = time.perf_counter() - t0         # the host thread is done enqueueing: close to dt = the step is host- (dispatch-) bound
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -370,6 +384,7 @@ def main():
         res = dict(metric="pretrain samples/sec (T=100 bins/modality, d_model=256, 5+5 layers, spike+behaviour masked pretraining step)",
                    value=round(value, 2), unit="samples/s", n_gpus=world, steps=a.steps, warmup=a.warmup, ms_per_step=round(ms, 3),
                    higher_is_better=True, scaling="weak", vs_baseline=None, dtype=a.dtype, data="synthetic",
+                   host_enqueue_ms_per_step=round(dt_host / a.steps * 1e3, 3),
                    config=dict(workload="BASELINE.json configs[1]: 1 session, ap(668 neurons)+behaviour(2), d_model=256, heads=8, mlp=512, "
                                         "5 enc + 5 dec layers, T=100 (L=200 tokens), dropout 0.4/0.2, AdamW+OneCycleLR, mixed objectives",
                                per_gpu_batch=B, global_batch=B * world, seq_len=200, parallelism=f"dp{world}"),
