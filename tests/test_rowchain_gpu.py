@@ -219,6 +219,35 @@ def test_mlp_backward_front_half_plus_rowgemm(ops, R, p):
         check(dxh[:R], xd.grad, 1.2e-2, "dx (front half + rowgemm) vs autograd")
 
 
+@pytest.mark.parametrize("R", [70_000, 84_736 - 5, 204_800, 131_072 - 17])
+def test_mlp_large_ragged_sizes_every_row(ops, R):
+    """Launches of more than one round of passes with a ragged last round (workgroups with one pass more than others, a last pass
+    with idle waves, a partial last tile).  Every row must come out exactly as a launch over just its neighbourhood produces it (rows
+    are independent; rotate = 0 so that the order in which a workgroup walks the intermediate tiles - and with it the fp32 summation
+    order - does not depend on which workgroup owns a row), nothing may be written past R, and no row may be skipped."""
+    x, Wu, bu, Wd, bd, g, bt, up, dn = mlp_setup(ops, R, seed=90)
+    y, xhat, rstd = torch.full((R + 2, 256), 3.0, device="cuda", dtype=BF), torch.full((R, 256), 7.0, device="cuda", dtype=BF), torch.full((R,), -1.0, device="cuda")
+    ops.mlp_fwd(ops.mlp_desc(R, x=x, w_up=up["Wp"], b_up=up["bp"], w_down=dn["WpP"], b_down=dn["bp"], y=y, xhat=xhat, rstd=rstd, rotate=0))
+    assert torch.all(y[R:] == 3.0) and torch.all(rstd > 0)
+    dy = rnd(R, 256, seed=91).to(BF)
+    mk = lambda n: torch.full((R + 1, n), 5.0, device="cuda", dtype=BF)
+    t1, gg, du = mk(256), mk(512), mk(512)
+    ops.mlp_bwd(ops.mlp_desc(R, w_up=up["Wp"], b_up=up["bp"], xhat=xhat, dy=dy, w_down_t=dn["WpT"], t1=t1, g=gg, du=du, dx=None, rotate=0))
+    assert torch.equal(t1[:R], dy)
+    for b in (t1, gg, du):
+        assert torch.all(b[R:] == 5.0)
+    for r0 in (0, 65_536 - 96, R - 1000):                                 # first round, the round boundary, the tail
+        n = min(1000, R - r0)
+        ys, xs, rs_ = torch.empty(n, 256, device="cuda", dtype=BF), torch.empty(n, 256, device="cuda", dtype=BF), torch.empty(n, device="cuda")
+        ops.mlp_fwd(ops.mlp_desc(n, x=x[r0:r0 + n], w_up=up["Wp"], b_up=up["bp"], w_down=dn["WpP"], b_down=dn["bp"], y=ys, xhat=xs, rstd=rs_, rotate=0))
+        assert torch.equal(ys, y[r0:r0 + n]) and torch.equal(xs, xhat[r0:r0 + n]) and torch.equal(rs_, rstd[r0:r0 + n])
+        g2, d2, t2 = torch.empty(n, 512, device="cuda", dtype=BF), torch.empty(n, 512, device="cuda", dtype=BF), torch.empty(n, 256, device="cuda", dtype=BF)
+        ops.mlp_bwd(ops.mlp_desc(n, w_up=up["Wp"], b_up=up["bp"], xhat=xs, dy=dy[r0:r0 + n], w_down_t=dn["WpT"], t1=t2, g=g2, du=d2, dx=None, rotate=0))
+        assert torch.equal(g2, gg[r0:r0 + n]) and torch.equal(d2, du[r0:r0 + n])
+    # no row skipped anywhere: g = gelu(u) of a random row is never exactly the fill value in all 512 columns
+    assert not torch.any(torch.all(gg[:R] == 5.0, dim=1)) and not torch.any(torch.all(xhat == 7.0, dim=1))
+
+
 def test_ln_linear_grad_matches_autograd(ops):
     """dW, db of the linear and dgamma, dbeta of the LayerNorm in front of it from G = dY^T x_hat and db = colsum dY."""
     R, N, K = 700, 96, 256
