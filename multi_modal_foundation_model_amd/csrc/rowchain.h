@@ -291,6 +291,14 @@ struct AChunk2 { AChunk s[2]; };
         SLOT = ring_lds + (uint32_t)(ring_cc % RINGA_SLOTS) * CHUNK;                         \
         ++ring_cc
 #define RINGA_PIECE(Q) dma_piece<RING_NT>(ring_nd, ring_nc, ring_al, wave, (Q))
+// the same without the wait: for kernels whose EXTRA depends on a wave-uniform condition (they issue vm_wait_n<...>() themselves first)
+#define RINGA_SYNC_NOWAIT(SRC, SLOT)                                                         \
+        __builtin_amdgcn_s_barrier();                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        const AChunk ring_nc = SRC(min(ring_cc + 2, ring_last));                             \
+        const uint32_t ring_nd = ring_lds + (uint32_t)((ring_cc + 2) % RINGA_SLOTS) * CHUNK; \
+        SLOT = ring_lds + (uint32_t)(ring_cc % RINGA_SLOTS) * CHUNK;                         \
+        ++ring_cc
 // ... and for the 32 KB chunks: pieces q = 0 .. 2 PP - 1 (sub-block q / PP)
 #define RINGA2_SYNC(SRC, SLOT)                                                               \
         vm_wait_n<2048 / RING_NT>();                                                         \

@@ -13,6 +13,7 @@
 #include "rowchain.h"
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 
 using namespace rowchain;
 
@@ -95,6 +96,111 @@ __global__ __launch_bounds__(NWV * 64, (KP == 1 ? 2 : 1)) void rowgemm_kernel(co
         }
     }
 }
+
+// ------------------------------------------------------------------------------------------------ forward-type kernel, asynchronous ring
+// K = 256 (every forward-type launch of the step).  Same row ownership and epilogue as rowgemm_kernel; the weights come through the
+// three-slot LDS-DMA ring of rowchain.h (chunk cc+2 requested - one request behind each MFMA group - while chunk cc is multiplied; no
+// staging registers, no ds_write pass; the move that took the MLP forward from 251 to 213 us).  A vector-memory LOAD inside the ring
+// loop would be waited for with a compiler-counted vmcnt that does not know the DMA requests, i.e. it would drain the prefetch: the
+// residual lines of the whole pass are therefore requested in front of the loop (RES4: N = 256, the only residual site), and the only
+// other traffic of the loop, the four line stores behind each tile pair, is accounted for in the ring's wait (EXTRA, below).
+// NPV = N / 64 when known at compile time (4: unrolled, residual allowed), 0 = runtime.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+template <bool LN, bool NTS, int NPV>
+__global__ __launch_bounds__(256, 2) void rowgemm_a_kernel(const mmfm_rowgemm_desc d) {
+    constexpr int NT = 256, NW = 4, RING_B = RINGA_SLOTS * CHUNK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // RING_B + NW * STG_BYTES + BIAS_MAX * 4
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
+    const int npair = NPV ? NPV : (d.N >> 6), cpp = 2 * npair;                      // N % 64 == 0
+    const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
+    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
+    if (my_passes == 0) return;
+    const __amdgpu_buffer_rsrc_t rs_w = wbuf(d.w);
+    const uint32_t ldwb = (uint32_t)d.ldw * 2u;
+    const int rot = d.rotate ? (int)(blockIdx.x % npair) : 0;
+    auto src = [=](int g) {
+        const int ti = g % cpp;
+        int pr = (ti >> 1) + rot; pr = pr >= npair ? pr - npair : pr;
+        AChunk c;
+        c.rs = rs_w; c.off = (uint32_t)(32 * (2 * pr + (ti & 1))) * ldwb; c.ldb = ldwb; c.kind = 0;
+        return c;
+    };
+    char* stg = smem + RING_B + wave * STG_BYTES;
+    float* lbias = reinterpret_cast<float*>(smem + RING_B + NW * STG_BYTES);
+    stage_vec(lbias, d.bias, d.N, t, NT);           // visible after the first chunk's barrier
+    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), RES = gbuf(d.residual, d.R * d.ldr * 2);
+    const GBuf XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4);
+    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2, ldrb = d.ldr * 2;
+    const bool has_res = NPV == 4 && d.residual != nullptr;
+    const ALane<NT> ring_al = alane_init<NT>(t, ldwb, 0u);
+    const AFrag fr = afrag_init(m, h);
+    RINGA_DECL(NT);
+    RINGA_START((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem, my_passes * cpp, src);
+    for (int pi = 0; pi < my_passes; ++pi) {
+        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
+        const bool live = wrow0 < (uint32_t)d.R;          // wave-uniform: a wave without rows only keeps the ring turning
+        opnd x[16];
+        Lines res[NPV ? NPV : 1];
+        if (live) {
+            load_rows_lines<4>(stg, x, X, wrow0, ldxb, lane, m, h);
+            if constexpr (LN) {
+                const float rs = ln_rows(x, d.eps);
+                store_rows_lines<4, true>(stg, XH, wrow0, 512u, lane, m, h, x);
+                st4f(RS, h == 0 ? (wrow0 + m) * 4u : 0xfffffff0u, rs);
+            }
+            if constexpr (NPV != 0) if (has_res) {          // behind the LayerNorm: its fp32 row and these 64 registers do not fit together
+#pragma unroll
+                for (int tp = 0; tp < NPV; ++tp) {
+                    int pr = tp + rot; pr = pr >= npair ? pr - npair : pr;
+                    res[tp] = fetch_lines(RES, wrow0, ldrb, 128u * pr, lane);
+                }
+            }
+        }
+        // One tile pair = two ring steps + four line stores.  The stores of pair tp-1 were issued behind the requests of chunks 2tp and
+        // 2tp+1, so both steps of pair tp may leave them in flight (EXTRA = 4; a wave without rows has issued none: 0); the first pair
+        // of a pass waits conservatively (its predecessors are the prologue's loads / stores, of which there may be none).
+        auto pair = [&](int tp, auto first) {
+            constexpr int EX = decltype(first)::value ? 0 : 4;
+            int pr = tp + rot; pr = pr >= npair ? pr - npair : pr;
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                uint32_t slot;
+                if (live) vm_wait_n<1024 / NT + EX>(); else vm_wait_n<1024 / NT>();
+                RINGA_SYNC_NOWAIT(src, slot);
+                if (live) {
+                    acc[j] = mma16a<4>(slot, fr, x, zero16(), [&](int g_) { RINGA_PIECE(g_); });
+                    add_vec(acc[j], lbias, 2 * pr + j, h);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 1024 / NT; ++q) RINGA_PIECE(q);
+                }
+            }
+            if (!live) return;
+            if constexpr (NPV != 0) if (has_res) {
+                stage_lines(stg, res[NPV ? tp : 0], lane);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x16 r = unstage_tile(stg, j, m, h);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) acc[j][i] += r[i];
+                }
+            }
+            stage_tile(stg, 0, m, h, acc[0]);
+            stage_tile(stg, 1, m, h, acc[1]);
+            flush_lines<NTS>(stg, Y, wrow0, ldyb, 128u * pr, lane);
+        };
+        pair(0, std::true_type());
+        if constexpr (NPV != 0) {
+#pragma unroll
+            for (int tp = 1; tp < NPV; ++tp) pair(tp, std::false_type());
+        } else {
+            for (int tp = 1; tp < npair; ++tp) pair(tp, std::false_type());
+        }
+    }
+}
+#pragma clang diagnostic pop
 
 // ------------------------------------------------------------------------------------------------ dX + LayerNorm backward
 // v = x . W^T (N = 256: the gradient wrt x_hat of the LayerNorm that fed the forward linear; W = prepared W'^T);
@@ -384,7 +490,21 @@ extern "C" int mmfm_rowgemm(const mmfm_rowgemm_desc* dp, mmfm_stream stream) {
             if (d.K == 512) { RG_LAUNCH(2, false) } else { RG_LAUNCH(3, false) }
         } else {
             dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 2, 4)), block(256);
-            if (d.ln) { RG_LAUNCH(1, true) } else { RG_LAUNCH(1, false) }
+            static const int ring_env = [] { const char* e = getenv("MMFM_ROWGEMM_RING"); return e ? atoi(e) : 1; }();   // 0: register-staged ring
+            if (ring_env && (!d.residual || (d.N == 256 && !d.ln))) {     // LayerNorm + residual (one launch per step) stays on the staged ring: 171 spills
+                constexpr int LDS_A = RINGA_SLOTS * CHUNK + 4 * STG_BYTES + BIAS_MAX * 4;
+#define RGA_LAUNCH(LN, NTS, NPV)                                                                                            \
+                {                                                                                                          \
+                    if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(rowgemm_a_kernel<LN, NTS, NPV>), LDS_A, "mmfm_rowgemm")) return rc; \
+                    hipLaunchKernelGGL((rowgemm_a_kernel<LN, NTS, NPV>), grid, block, LDS_A, st, d);                        \
+                }
+#define RGA_LAUNCH2(LN, NPV) if (d.stream_out) RGA_LAUNCH(LN, true, NPV) else RGA_LAUNCH(LN, false, NPV)
+                if (d.residual) RGA_LAUNCH2(false, 4)
+                else if (d.ln) RGA_LAUNCH2(true, 0)
+                else RGA_LAUNCH2(false, 0)
+#undef RGA_LAUNCH2
+#undef RGA_LAUNCH
+            } else if (d.ln) { RG_LAUNCH(1, true) } else { RG_LAUNCH(1, false) }
         }
 #undef RG_LAUNCH
     }
