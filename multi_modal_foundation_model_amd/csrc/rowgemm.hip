@@ -290,6 +290,101 @@ __global__ __launch_bounds__(NT) void rowgemm_lnbwd_kernel(const mmfm_rowgemm_de
     }
 }
 
+// ------------------------------------------------------------------------------------------------ dX + LayerNorm backward, asynchronous ring
+// The one-wave-per-tile kernel above with the weights on the three-slot LDS-DMA ring.  The x_hat lines of the pass are fetched and
+// stashed in front of the ring loop (a load inside it would be waited for with a vmcnt that does not know the DMA requests and drain
+// the prefetch), so the loop issues nothing but ring requests and MFMAs.
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+template <int KP>
+__global__ __launch_bounds__(NT) void rowgemm_lnbwd_a_kernel(const mmfm_rowgemm_desc d) {
+    constexpr int RING_B = RINGA_SLOTS * CHUNK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // RING_B + NW * STG_BYTES + NW * 4 * STG_BYTES
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
+    constexpr int cpp = 8 * KP;
+    const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
+    const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
+    if (my_passes == 0) return;
+    const __amdgpu_buffer_rsrc_t rs_w = wbuf(d.w);
+    const uint32_t ldwb = (uint32_t)d.ldw * 2u;
+    auto src = [=](int g) {
+        const int idx = g % cpp, tt = idx / KP, p = idx - tt * KP;
+        AChunk c;
+        c.rs = rs_w; c.off = (uint32_t)(32 * tt) * ldwb + 512u * (uint32_t)p; c.ldb = ldwb; c.kind = 0;
+        return c;
+    };
+    char* stg = smem + RING_B + wave * STG_BYTES;
+    char* xstash = smem + RING_B + NW * STG_BYTES + wave * 4 * STG_BYTES;
+    const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), RES = gbuf(d.residual, d.R * d.ldr * 2);
+    const GBuf XH = gbuf(d.bwd_xhat, d.R * 512), RS = gbuf(d.bwd_rstd, d.R * 4);
+    const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2, ldrb = d.ldr * 2;
+    const ALane<NT> ring_al = alane_init<NT>(t, ldwb, 0u);
+    const AFrag fr = afrag_init(m, h);
+    RINGA_DECL(NT);
+    RINGA_START((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem, my_passes * cpp, src);
+    for (int pi = 0; pi < my_passes; ++pi) {
+        const uint32_t wrow0 = (uint32_t)(((int64_t)(blockIdx.x + (int64_t)pi * gridDim.x) * NW + wave) * 32);
+        opnd x[16 * KP];
+        {
+            Lines xl[4];
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) xl[tp] = fetch_lines(XH, wrow0, 512u, 128u * tp, lane);
+            load_rows_lines<4 * KP>(stg, x, X, wrow0, ldxb, lane, m, h);
+#pragma unroll
+            for (int tp = 0; tp < 4; ++tp) stage_lines(xstash + tp * STG_BYTES, xl[tp], lane);
+        }
+        const float rs = ld4f(RS, (wrow0 + m) * 4u);
+        f32x16 acc[8];
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            acc[tt] = zero16();
+#pragma unroll
+            for (int p = 0; p < KP; ++p) {
+                uint32_t slot;
+                RINGA_SYNC(src, slot, 0);
+                acc[tt] = mma16a<4>(slot, fr, x + 16 * p, acc[tt], [&](int g_) { RINGA_PIECE(g_); });
+            }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 xt = unstage_tile(xstash + tp * STG_BYTES, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { s1 += acc[2 * tp + j][i]; s2 = fmaf(acc[2 * tp + j][i], xt[i], s2); }
+            }
+        }
+        s1 = xhalf(s1) * (1.f / 256.f);
+        s2 = xhalf(s2) * (1.f / 256.f);
+        Lines rl4[4];                                   // the residual-gradient lines, requested together (the operand registers are dead here)
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) rl4[tp] = fetch_lines(RES, wrow0, ldrb, 128u * tp, lane);
+#pragma unroll
+        for (int tp = 0; tp < 4; ++tp) {
+            const Lines& rl = rl4[tp];
+            f32x16 o[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 xt = unstage_tile(xstash + tp * STG_BYTES, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[j][i] = rs * (acc[2 * tp + j][i] - s1 - xt[i] * s2);
+            }
+            stage_lines(stg, rl, lane);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const f32x16 r = unstage_tile(stg, j, m, h);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[j][i] += r[i];
+            }
+            stage_tile(stg, 0, m, h, o[0]);
+            stage_tile(stg, 1, m, h, o[1]);
+            flush_lines<false>(stg, Y, wrow0, ldyb, 128u * tp, lane);
+        }
+    }
+}
+#pragma clang diagnostic pop
+
 // ------------------------------------------------------------------------------------------------ dX + LayerNorm backward, wave pairs
 // Eight waves; waves w and w+4 own the SAME 32 rows and split the 256 output columns (tiles 0-3 / 4-7): 64 accumulator
 // registers each instead of 128, the K = 256*KP input streamed one 256-wide piece at a time (64 registers + the next piece in
@@ -478,7 +573,15 @@ extern "C" int mmfm_rowgemm(const mmfm_rowgemm_desc* dp, mmfm_stream stream) {
             hipLaunchKernelGGL(rowgemm_lnbwd8_kernel<1>, grid, block, 0, st, d);
         } else {
             dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 1)), block(NT);
-            if (d.K == 512) hipLaunchKernelGGL(rowgemm_lnbwd_kernel<2>, grid, block, 0, st, d);
+            static const int ring_env = [] { const char* e = getenv("MMFM_ROWGEMM_RING"); return (e ? atoi(e) : 3) & 2; }();   // bit 1 clear: register-staged ring
+            constexpr int LDS_L = RINGA_SLOTS * CHUNK + NW * STG_BYTES + NW * 4 * STG_BYTES;
+            if (ring_env && d.K == 512) {
+                if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(rowgemm_lnbwd_a_kernel<2>), LDS_L, "mmfm_rowgemm")) return rc;
+                hipLaunchKernelGGL(rowgemm_lnbwd_a_kernel<2>, grid, block, LDS_L, st, d);
+            } else if (ring_env) {
+                if (int rc = mmfm_lds_opt_in(reinterpret_cast<const void*>(rowgemm_lnbwd_a_kernel<3>), LDS_L, "mmfm_rowgemm")) return rc;
+                hipLaunchKernelGGL(rowgemm_lnbwd_a_kernel<3>, grid, block, LDS_L, st, d);
+            } else if (d.K == 512) hipLaunchKernelGGL(rowgemm_lnbwd_kernel<2>, grid, block, 0, st, d);
             else hipLaunchKernelGGL(rowgemm_lnbwd_kernel<3>, grid, block, 0, st, d);
         }
     } else {
@@ -490,7 +593,7 @@ extern "C" int mmfm_rowgemm(const mmfm_rowgemm_desc* dp, mmfm_stream stream) {
             if (d.K == 512) { RG_LAUNCH(2, false) } else { RG_LAUNCH(3, false) }
         } else {
             dim3 grid(grid_for(d.R, per_cu_env > 0 ? per_cu_env : 2, 4)), block(256);
-            static const int ring_env = [] { const char* e = getenv("MMFM_ROWGEMM_RING"); return e ? atoi(e) : 1; }();   // 0: register-staged ring
+            static const int ring_env = [] { const char* e = getenv("MMFM_ROWGEMM_RING"); return (e ? atoi(e) : 3) & 1; }();   // bit 0 clear: register-staged ring
             if (ring_env && (!d.residual || (d.N == 256 && !d.ln))) {     // LayerNorm + residual (one launch per step) stays on the staged ring: 171 spills
                 constexpr int LDS_A = RINGA_SLOTS * CHUNK + 4 * STG_BYTES + BIAS_MAX * 4;
 #define RGA_LAUNCH(LN, NTS, NPV)                                                                                            \
