@@ -105,6 +105,10 @@ def kernel_profile(engine, plan, reps=3):
             flops = 4.0 * d.R * 256 * 512           # algorithmic: two products each way (the backward's recompute of up() is not counted)
             sub = "row MLP fwd" if name.endswith("fwd") else "row MLP bwd (dX chain)"
             nbytes = 2.0 * d.R * 256 * (3 if name.endswith("fwd") else 4) + (2.0 * d.R * 512 * 2 if name.endswith("bwd") else 0)
+            if name.endswith("bwd") and not d.dx:   # front half only (t1, g, du): ONE algorithmic product; d(x_hat) + LayerNorm backward is the
+                flops = 2.0 * d.R * 256 * 512       # mmfm_rowgemm launch behind it, which counts its own flops and bytes (it re-reads du)
+                sub = "row MLP bwd front half (t1, g, du)"
+                nbytes = 2.0 * d.R * 256 * 3 + 2.0 * d.R * 512 * 2
         elif name in ("mmfm_attn_fwd", "mmfm_attn_bwd"):
             d = keep[0]
             flops = (4.0 if name.endswith("fwd") else 10.0) * d.B * d.heads * d.Lq * d.Lk * d.dh
