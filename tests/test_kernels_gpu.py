@@ -773,7 +773,7 @@ def _unpack_keepbits(kb, B, heads, Lq, Lk):
 
 
 @pytest.mark.parametrize("B,heads,Lq,Lk,flags,pad", [(2, 8, 200, 200, 1, True), (2, 8, 200, 200, 0, False), (3, 4, 72, 40, 0, True), (2, 4, 224, 224, 1, False),
-                                                     (2, 2, 104, 104, 1, True)])
+                                                     (2, 2, 104, 104, 1, True), (80, 8, 200, 200, 1, True)])      # 640 heads: more than a persistent grid
 def test_attention_fast_dropout_matches_reference(ops, B, heads, Lq, Lk, flags, pad):
     """The dh = 32 fast pair (csrc/attention_fast.hip) WITH attention-probability dropout against torch fp32 on the same bf16 inputs:
     the keep mask is read off the kernel (see _extract_attn_keep_mask), then softmax -> mask / (1 - p) -> P.V and its autograd give
