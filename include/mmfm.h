@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define MMFM_VERSION 400
+#define MMFM_VERSION 401
 #define MMFM_F32 0
 #define MMFM_BF16 1
 

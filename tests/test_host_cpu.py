@@ -18,7 +18,7 @@ def test_library_exports_every_header_symbol():
     assert len(syms) >= 25
     assert [s for s in syms if not hasattr(lib, s)] == []
     assert set(syms) == set(L._PROTOS), "ctypes prototypes and include/mmfm.h must list the same functions"
-    assert lib.mmfm_version() == 400
+    assert lib.mmfm_version() == 401
     assert lib.mmfm_last_error() is not None
 
 
