@@ -10,7 +10,8 @@
 //   y = x + dropout(Y + b_down): HBM traffic 2 x R x 256 x 2 B (+ the x_hat side output for the backward) instead of the
 //   un-fused LN (2) + up (5) + down (4) = 11 x R x 256 x 2 B.
 // backward recomputes U_t / g_t from the saved x_hat (48 MFMAs per t instead of 32) and does the LayerNorm backward on the
-// accumulated d(x_hat) row in registers.
+// accumulated d(x_hat) row in registers - or, with dx == NULL (the engine's default since round 4), stops after t1 / g / du in an
+// eight-wave kernel and leaves d(x_hat) + the LayerNorm backward to mmfm_rowgemm(ln_bwd, K = 512).
 #ifdef MMFM_STAMP
 #define RING_BARRIER_STAMP STAMP(7)
 #endif

@@ -560,10 +560,11 @@ extern "C" int mmfm_rowgemm(const mmfm_rowgemm_desc* dp, mmfm_stream stream) {
     const int64_t maxld = std::max<int64_t>(std::max(d.ldx, d.ldy), std::max(d.ldr, 256));
     MMFM_REQUIRE((d.R + 128) * maxld * 2 < (int64_t)1 << 31, "mmfm_rowgemm: tensors beyond 2 GiB are not addressable by the 32-bit buffer offsets");
     MMFM_REQUIRE(d.N <= BIAS_MAX, "mmfm_rowgemm: N = %d > %d", d.N, BIAS_MAX);
-    // Launch shapes (measured on MI355X at R = 204,800, scripts/rowchain_bench.py; the rejected variants - 8 skewed waves, a dedicated
-    // weight-stager wave, 8-wave forward - are described in DESIGN.md section 3b and no longer compiled):
-    //   forward-type : 4 waves, 2 workgroups per CU at K = 256 (LN+q 78 us, LN+kv 117 us, out_proj 71 us), 1 per CU at K = 512 / 768
-    //   LN-backward epilogue : K = 256 -> wave pairs (8 waves, 101 us); K = 512 / 768 -> one wave per row tile (172 / 284 us)
+    // Launch shapes (measured on MI355X at R = 204,800 inside the bench step, profiles/r04_step_launches_B1024.txt; rejected variants - 8 skewed
+    // waves, a dedicated weight-stager wave, one 8-wave workgroup per CU, wave pairs at K >= 512 - are described in DESIGN.md sections 3b / 3e):
+    //   forward-type, K = 256 : 4 waves, 2 workgroups per CU, LDS-DMA ring (LN+qkv 119 us, LN+kv 94 us, LN+q 62 us, out_proj + residual 69 us,
+    //                           plain 56 us); LayerNorm + residual in one launch, and K = 512 / 768: the register-staged ring
+    //   LN-backward epilogue  : K = 256 -> wave pairs (8 waves, 101 us); K = 512 / 768 -> one wave per row tile on the LDS-DMA ring (137 / 174 us)
     static const int per_cu_env = [] { const char* e = getenv("MMFM_ROWGEMM_WG_PER_CU"); return e ? atoi(e) : 0; }();
     hipStream_t st = (hipStream_t)stream;
     if (d.ln_bwd) {
