@@ -434,11 +434,13 @@ def main():
                 pmc = None
                 if tj is not None and sub_names is None and all(k in tj for k in names if k in agg):
                     pmc = sum(tj[k] * agg[k][0] for k in names if k in agg)
-                byts = pmc if pmc is not None else nb
+                byts = nb                      # `hbm_gbs` / `hbm_frac` are ALGORITHMIC bytes over time; the PMC figure rides along as `traffic_*`
                 tf, gbs = fl / (ms * 1e-3) / 1e12, byts / (ms * 1e-3) / 1e9
                 out = dict(family=label, launches_per_step=n, ms_per_step=round(ms, 3), tflops=round(tf, 1), mfma_frac=round(tf / PEAK_TFLOPS[a.dtype], 4),
                            hbm_gbs=round(gbs, 1), hbm_frac=round(gbs / HBM_PEAK_GBS, 4), bytes_per_launch=int(byts / n),
-                           bytes_source="pmc" if pmc is not None else "algorithmic", flop_per_byte=round(fl / max(byts, 1.0), 1))
+                           bytes_source="algorithmic", flop_per_byte=round(fl / max(byts, 1.0), 1))
+                if pmc is not None:
+                    out.update(traffic_bytes_per_launch=int(pmc / n), traffic_over_algorithmic=round(pmc / max(nb, 1.0), 3))
                 out["bound"] = "mfma" if fl / max(byts, 1.0) >= RIDGE else "hbm"
                 if valu_slots is not None:
                     # issue floor: vector issue slots per score element x elements, one slot = 4 cycles of one of the chip's 1,024 SIMDs
@@ -467,7 +469,7 @@ def main():
             traffic = None
             if tj is not None and all(n in tj for n in FAM if n in agg):
                 traffic = int(sum(tj[n] * agg[n][0] for n in FAM if n in agg) / max(1, v[0]))
-            byts = traffic * v[0] if traffic is not None else v[3]
+            byts = v[3]                        # achieved = ALGORITHMIC bytes per launch / average launch time; `traffic` = HBM bytes by PMC, beside it
             tf, gbs = v[2] / (v[1] * 1e-3) / 1e12, byts / (v[1] * 1e-3) / 1e9
             hbm_bound = v[2] / max(byts, 1.0) < RIDGE
             # the dominant family against ITS roof: HBM when its arithmetic intensity sits under the ridge (it does: ~140 flop/B)
