@@ -112,16 +112,21 @@ __global__ __launch_bounds__(256, 2) void rowgemm_a_kernel(const mmfm_rowgemm_de
     constexpr int NT = 256, NW = 4, RING_B = RINGA_SLOTS * CHUNK;
     extern __shared__ __attribute__((aligned(16))) char smem[];       // RING_B + NW * STG_BYTES + BIAS_MAX * 4
     const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), m = lane & 31, h = lane >> 5;
-    const int npair = NPV ? NPV : (d.N >> 6), cpp = 2 * npair;                      // N % 64 == 0
+    // Column blocks (gridDim.y > 1: launches with fewer row passes than CUs - the reference's batch of 16 is 25 passes - where one workgroup
+    // walking all of N is a chain of 2 N / 64 dependent ring steps; split, every workgroup re-reads its 128 rows and takes `npair` tile pairs
+    // starting at `pbase`).  The LayerNorm side outputs are written by column block 0 only.
+    const int np_all = d.N >> 6;                                                    // N % 64 == 0
+    const int npb = NPV ? NPV : (np_all + (int)gridDim.y - 1) / (int)gridDim.y, pbase = (int)blockIdx.y * npb;
+    const int npair = NPV ? NPV : min(npb, np_all - pbase), cpp = 2 * npair;
     const int64_t npass = (d.R + 32 * NW - 1) / (32 * NW);
     const int my_passes = blockIdx.x < npass ? (int)((npass - 1 - blockIdx.x) / gridDim.x) + 1 : 0;
-    if (my_passes == 0) return;
+    if (my_passes == 0 || npair <= 0) return;
     const __amdgpu_buffer_rsrc_t rs_w = wbuf(d.w);
     const uint32_t ldwb = (uint32_t)d.ldw * 2u;
     const int rot = d.rotate ? (int)(blockIdx.x % npair) : 0;
     auto src = [=](int g) {
         const int ti = g % cpp;
-        int pr = (ti >> 1) + rot; pr = pr >= npair ? pr - npair : pr;
+        int pr = (ti >> 1) + rot; pr = pbase + (pr >= npair ? pr - npair : pr);
         AChunk c;
         c.rs = rs_w; c.off = (uint32_t)(32 * (2 * pr + (ti & 1))) * ldwb; c.ldb = ldwb; c.kind = 0;
         return c;
@@ -130,9 +135,9 @@ __global__ __launch_bounds__(256, 2) void rowgemm_a_kernel(const mmfm_rowgemm_de
     float* lbias = reinterpret_cast<float*>(smem + RING_B + NW * STG_BYTES);
     stage_vec(lbias, d.bias, d.N, t, NT);           // visible after the first chunk's barrier
     const GBuf X = gbuf(d.x, d.R * d.ldx * 2), Y = gbuf(d.y, d.R * d.ldy * 2), RES = gbuf(d.residual, d.R * d.ldr * 2);
-    const GBuf XH = gbuf(d.xhat, d.R * 512), RS = gbuf(d.rstd, d.R * 4);
+    const GBuf XH = gbuf(blockIdx.y == 0 ? d.xhat : nullptr, d.R * 512), RS = gbuf(blockIdx.y == 0 ? d.rstd : nullptr, d.R * 4);
     const uint32_t ldxb = d.ldx * 2, ldyb = d.ldy * 2, ldrb = d.ldr * 2;
-    const bool has_res = NPV == 4 && d.residual != nullptr;
+    const bool has_res = NPV != 0 && d.residual != nullptr;
     const ALane<NT> ring_al = alane_init<NT>(t, ldwb, 0u);
     const AFrag fr = afrag_init(m, h);
     RINGA_DECL(NT);
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_a_kernel(const mmfm_rowgemm_de
             if constexpr (NPV != 0) if (has_res) {          // behind the LayerNorm: its fp32 row and these 64 registers do not fit together
 #pragma unroll
                 for (int tp = 0; tp < NPV; ++tp) {
-                    int pr = tp + rot; pr = pr >= npair ? pr - npair : pr;
+                    int pr = tp + rot; pr = pbase + (pr >= npair ? pr - npair : pr);
                     res[tp] = fetch_lines(RES, wrow0, ldrb, 128u * pr, lane);
                 }
             }
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void rowgemm_a_kernel(const mmfm_rowgemm_de
         // of a pass waits conservatively (its predecessors are the prologue's loads / stores, of which there may be none).
         auto pair = [&](int tp, auto first) {
             constexpr int EX = decltype(first)::value ? 0 : 4;
-            int pr = tp + rot; pr = pr >= npair ? pr - npair : pr;
+            int pr = tp + rot; pr = pbase + (pr >= npair ? pr - npair : pr);
             f32x16 acc[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -603,9 +608,18 @@ extern "C" int mmfm_rowgemm(const mmfm_rowgemm_desc* dp, mmfm_stream stream) {
                     hipLaunchKernelGGL((rowgemm_a_kernel<LN, NTS, NPV>), grid, block, LDS_A, st, d);                        \
                 }
 #define RGA_LAUNCH2(LN, NPV) if (d.stream_out) RGA_LAUNCH(LN, true, NPV) else RGA_LAUNCH(LN, false, NPV)
-                if (d.residual) RGA_LAUNCH2(false, 4)
-                else if (d.ln) RGA_LAUNCH2(true, 0)
-                else RGA_LAUNCH2(false, 0)
+                // fewer row passes than a quarter of the resident slots (2 workgroups per CU): split N into column blocks too (kernel comment)
+                const int64_t npass = (d.R + 127) / 128;
+                const int np_all = d.N >> 6;
+                static const int nsplit_env = [] { const char* e = getenv("MMFM_ROWGEMM_NSPLIT"); return e ? atoi(e) : 1; }();
+                const int ny = (nsplit_env && npass < 128) ? (int)std::max<int64_t>(1, std::min<int64_t>(np_all, 512 / npass)) : 1;
+                if (d.residual) {                                  // N = 256: four pairs in one block, or one pair in each of four
+                    if (ny >= 4) { grid.y = 4; RGA_LAUNCH2(false, 1) } else { RGA_LAUNCH2(false, 4) }
+                } else {
+                    grid.y = (unsigned)((np_all + (np_all + ny - 1) / ny - 1) / ((np_all + ny - 1) / ny));      // blocks of ceil(np_all / ny) pairs
+                    if (d.ln) RGA_LAUNCH2(true, 0)
+                    else RGA_LAUNCH2(false, 0)
+                }
 #undef RGA_LAUNCH2
 #undef RGA_LAUNCH
             } else if (d.ln) { RG_LAUNCH(1, true) } else { RG_LAUNCH(1, false) }

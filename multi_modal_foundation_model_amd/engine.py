@@ -304,8 +304,11 @@ class Engine:
         if self.dtype != "bf16" or c.hidden != 256 or c.inter != 512 or (R + 128) * 1024 * 2 >= 2 ** 31:
             return 0
         if R < 12288 and "MMFM_FUSED" not in os.environ:
-            return 0             # a row-owner pass is 128 rows: below ~100 passes per launch the grid cannot fill 256 CUs
-                                 # (measured, un-fused vs fused ms/step: B=16 4.80 / 5.00, B=32 5.24 / 5.32, B=64 6.31 / 6.21, B=128 8.55 / 7.66)
+            # a row-owner pass is 128 rows: below ~100 passes per launch the grid cannot fill 256 CUs.  Since round 4 the forward-type linears
+            # split N into column blocks there (rowgemm.hip), which makes the LayerNorm-fed linears and out_proj worth fusing at the reference's
+            # batch of 16 too; the MLP kernels (chained products, no column split) stay off.  ms/step un-fused / 11 / 15: B=16 4.45 / 4.08 / 4.19,
+            # B=32 4.85 / 4.71 / -, B=64 5.46 / 5.50 / 5.48 (R = 12,800: the default 15)
+            return 11
         return int(os.environ.get("MMFM_FUSED", "15")) & 15        # default: everything fused, the fastest end to end (35.6 vs 36.3 ms)
 
     # ------------------------------------------------------------------ bf16 transposes for the compute-bound dX products
