@@ -92,6 +92,14 @@ def test_rowgemm_layernorm_prologue(ops, R, N):
     torch.testing.assert_close(rstd.double(), (1 / torch.sqrt(var + 1e-5)).squeeze(1), rtol=1e-5, atol=1e-6)
     ref = F.layer_norm(xd, (256,), g.double(), bt.double(), 1e-5) @ W.double().T + bias.double() + res.double()
     check(y, ref, 6e-3, f"ln+linear {R}x{N}")
+    # without a residual the launch takes the LDS-DMA ring kernel, which at these sizes splits N into column blocks: x_hat / rstd are
+    # written by column block 0 only and must still be complete, every block's columns must land, nothing beyond R may be touched
+    y2, xhat2, rstd2 = (torch.full((R + 2, N), 9.0, device="cuda", dtype=BF), torch.full((R + 2, 256), 9.0, device="cuda", dtype=BF),
+                        torch.full((R + 2,), 9.0, device="cuda"))
+    ops.rowgemm(x, e["Wp"], y2, R, N, 256, bias=e["bp"], ln=True, xhat=xhat2, rstd=rstd2)
+    check(y2[:R], ref - res.double(), 6e-3, f"ln+linear (column blocks) {R}x{N}")
+    assert torch.equal(xhat2[:R], xhat) and torch.equal(rstd2[:R], rstd)
+    assert torch.all(y2[R:] == 9.0) and torch.all(xhat2[R:] == 9.0) and torch.all(rstd2[R:] == 9.0)
 
 
 @pytest.mark.parametrize("R,K", [(300, 256), (1000, 768), (129, 512)])
