@@ -597,6 +597,8 @@ class Engine:
             K.rowgemm(Xin, pw["Wp"], Yout, R, N, H, bias=pw["bp"], ln=True, xhat=xh, rstd=rs, residual=residual,
                       ldr=H if residual is not None else 0, stream_out=True, plan=plan)
 
+        late_lng: list = []
+
         def dlin_ln(plan, dYt, tag, wname, lnname, N):
             """Gradients of a LayerNorm-fed linear and of that LayerNorm's affine from G = dY^T x_hat (mmfm_ln_linear_grad)."""
             S, kchunk = self._dw_split(N, H, R)
@@ -617,6 +619,17 @@ class Engine:
             elif S == 1:
                 K.gemm(dYt, xh, gdb, N, H, R, lda=N, ldb=H, ldc=H, a_kcontig=0, b_kcontig=0, dtype=code, c_f32=1,
                        colsum=gdb.data_ptr() + 4 * N * H, plan=plan)
+            elif batch_red:
+                # launch-bound regime: the slabs join the segment's ONE reduction launch (own region, own reduced buffer per site) and
+                # mmfm_ln_linear_grad runs behind it at the end of the segment (close_segment) - one reduction launch per site less
+                stride = _align(N * H + N)
+                sl = slab_region(S, stride)
+                g_site = buf(f"ws/gdb/{len(late_lng)}", (gdb.numel(),), f32)
+                K.gemm(dYt, xh, sl, N, H, R, lda=N, ldb=H, ldc=H, a_kcontig=0, b_kcontig=0, splits=S, kchunk=kchunk,
+                       slab_stride=stride, dtype=code, c_f32=1, colsum=sl.data_ptr() + 4 * N * H, plan=plan)
+                pend.append((g_site, sl, N * H + N, S, stride, False))
+                late_lng.append((g_site, wname, lnname, N))
+                return
             else:
                 stride = _align(N * H + N)
                 slab_fits(slab, S, stride, wname)
@@ -746,6 +759,11 @@ class Engine:
             if pend:                          # the segment's weight-gradient slabs, all in one launch, before its DDP hook fires
                 K.reduce_slabs_multi(list(pend), self.device, plan=cur)
                 pend.clear()
+            for g_site, wname, lnname, N in late_lng:
+                K.ln_linear_grad(g_site, self.Pf(wname + ".weight"), self.Pf(lnname + ".weight"), self.Pf(lnname + ".bias"), N, H,
+                                 self.Gv(wname + ".weight"), self.Gv(wname + ".bias"), self.Gv(lnname + ".weight"), self.Gv(lnname + ".bias"),
+                                 ws_lng, plan=cur)
+            late_lng.clear()
             slabm_off[0] = 0                  # the reduction has consumed the regions (stream order): the next segment reuses them
             bwd.append((name, cur))
             cur = []
