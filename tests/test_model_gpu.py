@@ -167,6 +167,49 @@ def test_config5_bf16_train_steps_finite_and_close():
     assert losses[2] < losses[0]
 
 
+def test_config5_bf16_drift_against_fp32_engine_and_dropout_run():
+    """BASELINE configs[4] shapes (dh = 64, L = 600: csrc/attention_long.hip and the 256-tile GEMM) over TWELVE optimiser steps: the bf16
+    engine against this library's own fp32 parity engine on the same batches and masks (the fp32 engine is pinned to the reference by
+    test_config5_three_modalities_vs_reference_fixture) - every step within 2e-2, the mean relative gap within 8e-3.  Then the same
+    model with dropout 0.4 / 0.2: the keep-bit attention pair runs in training (one bit workspace per attention site), losses stay
+    finite and the first one sits where dropout puts it (within 30 % of the dropout-free value)."""
+    g = load_json("config5_scalars.json")
+    mods = [tuple(m) for m in g["mods"]]
+
+    def make(dtype, dropout, emb_dropout):
+        m = build_model_mods(model_config(H=512, heads=8, inter=1024, max_F=200, n_modality=3, dropout=dropout, emb_dropout=emb_dropout), mods,
+                             seed=g["model_seed"])
+        m.loss_mod["lfp"] = "mse"
+        m.compute_dtype = dtype
+        return m.cuda().train()
+
+    def run(model, steps):
+        opt, sch = make_optimizer(model, 20)
+        out_l = []
+        for s_ in range(steps):
+            batch = O.synth_batch_mods(g["B"], g["T"], mods, seed=g["batch_seed"] + s_, pad=g["pad"])
+            torch.manual_seed(g["masker_seed"] + s_)
+            out = model(to_dev(O.make_mod_dict_mods(batch, mods, ("ap", "lfp", None)[s_ % 3])))
+            out.loss.backward()
+            opt.step(); sch.step(); opt.zero_grad()
+            out_l.append(out.loss.item())
+        return np.array(out_l)
+
+    l32 = run(make("fp32", 0.0, 0.0), 12)
+    mb = make("bf16", 0.0, 0.0)
+    l16 = run(mb, 12)
+    assert np.isfinite(l32).all() and np.isfinite(l16).all()
+    rel = np.abs(l16 - l32) / np.abs(l32)
+    assert rel.max() < 2e-2, (l16, l32)
+    assert rel.mean() < 8e-3, rel
+    del mb
+    md = make("bf16", 0.4, 0.2)
+    ld = run(md, 6)
+    assert np.isfinite(ld).all()
+    assert ld[0] == pytest.approx(l16[0], rel=0.3)
+    assert any(k.endswith("/keep") for k in md._engine.b), "the keep-bit attention workspaces were not allocated: dropout ran on the hash path"
+
+
 def run_curve(model, steps, B, T, n_ap, n_beh, total_steps, objectives):
     opt, sch = make_optimizer(model, total_steps)
     model.train()
