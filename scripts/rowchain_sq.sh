@@ -15,4 +15,10 @@ for k, v in agg.items():
     if not any(s in k for s in ("rowgemm", "mlp_")): continue
     print(k)
     for c, x in sorted(v.items()): print(f"   {c:28s} {x / cnt[(k, c)]:16.0f}")
+    w = v.get("SQ_WAVE_CYCLES", 0) / max(cnt[(k, "SQ_WAVE_CYCLES")], 1)
+    if w:
+        f = lambda c: v.get(c, 0) / max(cnt[(k, c)], 1) / w
+        print(f"   -> of a wave's life: waiting (s_waitcnt / barrier) {f('SQ_WAIT_ANY'):.2f}, waiting for issue {f('SQ_WAIT_INST_ANY'):.2f}, issuing {f('SQ_ACTIVE_INST_ANY'):.2f}; "
+              f"MFMA pipe busy {v.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) / max(cnt[(k, 'SQ_VALU_MFMA_BUSY_CYCLES')], 1) / max(v.get('SQ_BUSY_CYCLES', 1) / max(cnt[(k, 'SQ_BUSY_CYCLES')], 1), 1) / 4:.2f} of SIMD time; "
+              f"LDS bank conflicts {v.get('SQ_LDS_BANK_CONFLICT', 0) / max(v.get('SQ_LDS_IDX_ACTIVE', 1), 1):.2f} of LDS active")
 PY
